@@ -1,0 +1,482 @@
+// Score normalisation kernels.
+//
+// Adaptive S-norm works on "rows over the cohort": A_ec[e, c] (enrol vs cohort) and A_tc[t, c]
+// (test vs cohort).  For every row the cohort members ranked discard .. discard+k-1 by descending
+// score are selected (top-k), then for every (row r of X, list q) pair the mean and standard
+// deviation of X[r, list_q] are gathered:
+//     Z part:  X = A_ec, lists from A_tc rows  -> stats[e, t]
+//     T part:  X = A_tc, lists from A_ec rows  -> stats[t, e]
+// and the final kernel combines both with the raw score.
+//
+//   topk_rows     one workgroup per row; the row lives in LDS as order-preserving integer keys and
+//                 an 8-bit-per-pass radix select finds the boundary keys; ties at a boundary are
+//                 resolved by cohort index (lowest first), so the result is deterministic.
+//   gather_stats  one workgroup per X row held in LDS; lanes walk different lists, whose indices
+//                 are stored list-minor ([k][Q]) so that a wave's index loads are coalesced.
+#include "common.h"
+
+namespace {
+
+constexpr int TK_THREADS = 256;
+
+__device__ __forceinline__ unsigned key_of(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending float order == ascending key
+}
+
+// Radix select of the element at descending rank `want` (0-based) among keys[0..n):
+// returns its key and the number of keys strictly greater.  All threads of the block call it.
+__device__ void select_rank(const unsigned* __restrict__ keys, int n, int want, unsigned* hist,
+                            unsigned* bcast, unsigned* out_key, int* out_gt) {
+    const int tid = threadIdx.x;
+    unsigned prefix = 0, mask = 0;
+    int gt = 0;  // keys known to be greater than every key matching `prefix`
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int b = tid; b < 256; b += TK_THREADS) hist[b] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += TK_THREADS) {
+            const unsigned kx = keys[i];
+            if ((kx & mask) == prefix) atomicAdd(&hist[(kx >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // wave 0: suffix sums over the 256 bins, 4 bins per lane (lane 63 owns bins 252..255)
+            const int lane = tid;
+            unsigned c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c[u] = hist[4 * lane + u];
+            const unsigned own = c[0] + c[1] + c[2] + c[3];
+            unsigned above = own;  // inclusive suffix sum over lanes >= lane
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned v = __shfl_down(above, off, 64);
+                if (lane + off < 64) above += v;
+            }
+            above -= own;  // keys in bins owned by higher lanes
+            const unsigned need = (unsigned)(want - gt);  // rank inside the current candidate set
+            // find the bin where the descending cumulative count first exceeds `need`
+            unsigned run = above;
+            int found = -1;
+            unsigned gt_in = 0;
+#pragma unroll
+            for (int u = 3; u >= 0; --u) {
+                if (found < 0 && run <= need && run + c[u] > need) {
+                    found = 4 * lane + u;
+                    gt_in = run;
+                }
+                run += c[u];
+            }
+            if (found >= 0) {  // exactly one lane finds it
+                bcast[0] = (unsigned)found;
+                bcast[1] = gt_in;
+            }
+        }
+        __syncthreads();
+        prefix |= bcast[0] << shift;
+        mask |= 255u << shift;
+        gt += (int)bcast[1];
+        __syncthreads();
+    }
+    *out_key = prefix;
+    *out_gt = gt;
+}
+
+// idx_t[j * ldi + row] (j < k) = cohort indices ranked discard .. discard+k-1 of row `row`,
+// in ascending index order.
+template <bool USE_LDS>
+__global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float* __restrict__ A, int64_t lda,
+                                                               int nc, int k, int discard,
+                                                               int32_t* __restrict__ idx_t, int64_t ldi,
+                                                               unsigned* __restrict__ gkeys) {
+    extern __shared__ __attribute__((aligned(16))) unsigned smem[];
+    unsigned* hist = smem;          // 256
+    unsigned* bcast = smem + 256;   // 4
+    unsigned* wtot = smem + 260;    // 4 waves x 2 counters (+ pad)
+    unsigned* keys = USE_LDS ? smem + 272 : gkeys + (int64_t)blockIdx.x * nc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = blockIdx.x;
+    const float* src = A + row * lda;
+    for (int i = tid; i < nc; i += TK_THREADS) keys[i] = key_of(src[i]);
+    __syncthreads();
+
+    unsigned key_hi, key_lo;
+    int gt_hi, gt_lo;
+    select_rank(keys, nc, discard + k - 1, hist, bcast, &key_hi, &gt_hi);
+    if (discard > 0) {
+        select_rank(keys, nc, discard, hist, bcast, &key_lo, &gt_lo);
+    } else {
+        key_lo = 0xffffffffu;
+        gt_lo = 0;
+    }
+    // ordered compaction: rank of an element with a boundary key = (#greater) + (#equal before it)
+    int eq_hi_seen = 0, eq_lo_seen = 0, written = 0;
+    const int last = discard + k;
+    for (int base = 0; base < nc; base += TK_THREADS) {
+        const int i = base + tid;
+        const unsigned kx = i < nc ? keys[i] : 0u;
+        const bool valid = i < nc;
+        const bool is_hi = valid && kx == key_hi;
+        const bool is_lo = valid && discard > 0 && kx == key_lo;
+        const unsigned long long m_hi = __ballot(is_hi), m_lo = __ballot(is_lo);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (lane == 0) {
+            wtot[2 * wave] = (unsigned)__popcll(m_hi);
+            wtot[2 * wave + 1] = (unsigned)__popcll(m_lo);
+        }
+        __syncthreads();
+        int hi_before = eq_hi_seen + __popcll(m_hi & below), lo_before = eq_lo_seen + __popcll(m_lo & below);
+        int hi_tot = 0, lo_tot = 0;
+#pragma unroll
+        for (int w = 0; w < TK_THREADS / 64; ++w) {
+            if (w < wave) {
+                hi_before += (int)wtot[2 * w];
+                lo_before += (int)wtot[2 * w + 1];
+            }
+            hi_tot += (int)wtot[2 * w];
+            lo_tot += (int)wtot[2 * w + 1];
+        }
+        bool sel = false;
+        if (valid) {
+            if (is_lo) {  // also covers key_lo == key_hi
+                const int rank = gt_lo + lo_before;
+                sel = rank >= discard && rank < last;
+            } else if (is_hi) {
+                sel = gt_hi + hi_before < last;
+            } else {
+                sel = kx > key_hi && kx < key_lo;
+            }
+        }
+        __syncthreads();  // wtot is rewritten below
+        const unsigned long long m_sel = __ballot(sel);
+        if (lane == 0) wtot[2 * wave] = (unsigned)__popcll(m_sel);
+        __syncthreads();
+        int pos = written + __popcll(m_sel & below), tot = 0;
+#pragma unroll
+        for (int w = 0; w < TK_THREADS / 64; ++w) {
+            if (w < wave) pos += (int)wtot[2 * w];
+            tot += (int)wtot[2 * w];
+        }
+        if (sel && pos < k) idx_t[(int64_t)pos * ldi + row] = i;
+        written += tot;
+        eq_hi_seen += hi_tot;
+        eq_lo_seen += lo_tot;
+        __syncthreads();
+    }
+}
+
+// One workgroup per X row (held in LDS), lanes over lists q.
+//   mean[r, q] = sum_j X[r, L[j, q]] / norm,  istd[r, q] = 1 / max(sqrt(sum x^2 / norm - mean^2), floor)
+// norm = k without mask, else the number of unmasked selected entries (mask row also in LDS).
+__global__ __launch_bounds__(256) void gather_stats_kernel(const float* __restrict__ X, int64_t ldx,
+                                                           const unsigned char* __restrict__ mask,
+                                                           int64_t ldm, int nc,
+                                                           const int32_t* __restrict__ idx_t,
+                                                           int64_t ldi, int k, int64_t Q,
+                                                           int64_t q_per_block, float floor_,
+                                                           float* __restrict__ mean,
+                                                           float* __restrict__ istd, int64_t ldo) {
+    extern __shared__ __attribute__((aligned(16))) float xrow[];
+    unsigned char* mrow = reinterpret_cast<unsigned char*>(xrow + nc);
+    const int tid = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    const float* src = X + r * ldx;
+    for (int i = tid; i < nc; i += 256) xrow[i] = src[i];
+    if (mask)
+        for (int i = tid; i < nc; i += 256) mrow[i] = mask[r * ldm + i];
+    __syncthreads();
+    const int64_t q0 = (int64_t)blockIdx.y * q_per_block;
+    const int64_t q1 = (q0 + q_per_block < Q) ? q0 + q_per_block : Q;
+    for (int64_t q = q0 + tid; q < q1; q += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        int cnt = 0;
+        const int32_t* lp = idx_t + q;
+        if (mask) {
+            for (int j = 0; j < k; ++j) {
+                const int c = lp[(int64_t)j * ldi];
+                const double v = (double)xrow[c];
+                s1 += v;
+                s2 += v * v;
+                cnt += mrow[c] ? 1 : 0;
+            }
+        } else {
+#pragma unroll 4
+            for (int j = 0; j < k; ++j) {
+                const int c = lp[(int64_t)j * ldi];
+                const double v = (double)xrow[c];
+                s1 += v;
+                s2 += v * v;
+            }
+            cnt = k;
+        }
+        const double m = s1 / (double)cnt;
+        double var = s2 / (double)cnt - m * m;
+        double sd = sqrt(var > 0.0 ? var : (var == var ? 0.0 : var));  // keep NaN (0/0) visible
+        if (sd < (double)floor_) sd = (double)floor_;
+        mean[r * ldo + q] = (float)m;
+        istd[r * ldo + q] = (float)(1.0 / sd);
+    }
+}
+
+// out[e, t] = ((S - mz[e,t]) * iz[e,t] + (S - mt[t,e]) * it[t,e]) / sqrt(2); the T-part statistics
+// arrive transposed and go through a 32 x 33 LDS tile.
+__global__ __launch_bounds__(256) void asnorm_apply_kernel(const float* __restrict__ S, int64_t lds_,
+                                                           int64_t ne, int64_t nt,
+                                                           const float* __restrict__ mz,
+                                                           const float* __restrict__ iz, int64_t ldz,
+                                                           const float* __restrict__ mt,
+                                                           const float* __restrict__ it, int64_t ldt,
+                                                           float* __restrict__ out, int64_t ldo) {
+    __shared__ float tm[32][33], ti[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int64_t e0 = (int64_t)blockIdx.y * 32, t0 = (int64_t)blockIdx.x * 32;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int64_t t = t0 + ty + 8 * p, e = e0 + tx;
+        const bool ok = t < nt && e < ne;
+        tm[ty + 8 * p][tx] = ok ? mt[t * ldt + e] : 0.f;
+        ti[ty + 8 * p][tx] = ok ? it[t * ldt + e] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int64_t e = e0 + ty + 8 * p, t = t0 + tx;
+        if (e < ne && t < nt) {
+            const float s = S[e * lds_ + t];
+            const float z = (s - mz[e * ldz + t]) * iz[e * ldz + t];
+            const float tn = (s - tm[tx][ty + 8 * p]) * ti[tx][ty + 8 * p];
+            out[e * ldo + t] = (z + tn) * 0.70710678118654752440f;
+        }
+    }
+}
+
+// 32 x 32 tiled transpose: out[c, r] = in[r, c]
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int64_t ldi,
+                                                        int64_t rows, int64_t cols,
+                                                        float* __restrict__ out, int64_t ldo) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int64_t r = r0 + ty + 8 * p, c = c0 + tx;
+        tile[ty + 8 * p][tx] = (r < rows && c < cols) ? in[r * ldi + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int64_t c = c0 + ty + 8 * p, r = r0 + tx;
+        if (c < cols && r < rows) out[c * ldo + r] = tile[tx][ty + 8 * p];
+    }
+}
+
+// One wavefront per row: mean and 1 / max(std, floor) over a whole row (non-adaptive Z/T-norm).
+// With a mask, masked entries count as zero and the moments are divided by the unmasked fraction.
+__global__ __launch_bounds__(256) void row_meanstd_kernel(const float* __restrict__ X, int64_t ldx,
+                                                          int64_t n_rows, int nc,
+                                                          const unsigned char* __restrict__ mask,
+                                                          int64_t ldm, float floor_,
+                                                          float* __restrict__ mean,
+                                                          float* __restrict__ istd) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const float* src = X + r * ldx;
+    double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+    for (int i = lane; i < nc; i += 64) {
+        const bool on = mask ? mask[r * ldm + i] != 0 : true;
+        const double v = on ? (double)src[i] : 0.0;
+        s1 += v;
+        s2 += v * v;
+        cnt += on ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off, 64);
+        s2 += __shfl_xor(s2, off, 64);
+        cnt += __shfl_xor(cnt, off, 64);
+    }
+    if (lane == 0) {
+        double m, var;
+        if (mask) {
+            m = s1 / cnt;
+            var = s2 / cnt - m * m;
+        } else {
+            // two-pass would need the row twice; the shifted one-pass form in double is exact enough
+            m = s1 / (double)nc;
+            var = s2 / (double)nc - m * m;
+        }
+        double sd = sqrt(var > 0.0 ? var : (var == var ? 0.0 : var));
+        if (sd < (double)floor_) sd = (double)floor_;
+        mean[r] = (float)m;
+        istd[r] = (float)(1.0 / sd);
+    }
+}
+
+// out = sum over enabled parts of (S - m) * i, divided by sqrt(2) when both are enabled
+__global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict__ S, int64_t lds_,
+                                                         int64_t ne, int64_t nt,
+                                                         const float* __restrict__ mz,
+                                                         const float* __restrict__ iz,
+                                                         const float* __restrict__ mt,
+                                                         const float* __restrict__ it,
+                                                         float* __restrict__ out, int64_t ldo) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t e = blockIdx.y;
+    if (t >= nt || e >= ne) return;
+    const float s = S[e * lds_ + t];
+    float acc = 0.f;
+    if (mz) acc += (s - mz[e]) * iz[e];
+    if (mt) acc += (s - mt[t]) * it[t];
+    if (mz && mt) acc *= 0.70710678118654752440f;
+    out[e * ldo + t] = acc;
+}
+
+// X[i, j] = 0 where mask[i, j] == 0
+__global__ __launch_bounds__(256) void mask_zero_kernel(float* __restrict__ X, int64_t ldx, int64_t rows,
+                                                        int64_t cols,
+                                                        const unsigned char* __restrict__ mask,
+                                                        int64_t ldm) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (i < rows && j < cols && mask[i * ldm + j] == 0) X[i * ldx + j] = 0.f;
+}
+
+constexpr int MAX_LDS_BYTES = 160 * 1024;
+
+}  // namespace
+
+extern "C" int64_t hypmi_topk_workspace_bytes(int64_t n_rows, int nc) {
+    const int64_t lds_need = (272 + (int64_t)nc) * 4;
+    return lds_need <= MAX_LDS_BYTES ? 0 : n_rows * (int64_t)nc * 4;
+}
+
+extern "C" int hypmi_topk_rows(const float* A, int64_t n_rows, int nc, int64_t lda, int k, int discard,
+                               int32_t* idx_t, int64_t ldi, void* workspace, int64_t workspace_bytes,
+                               void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HYPMI_REQUIRE(A && idx_t, "topk_rows: null pointer");
+    HYPMI_REQUIRE(n_rows >= 0 && nc > 0 && lda >= nc && ldi >= n_rows, "topk_rows: bad shape");
+    HYPMI_REQUIRE(k > 0 && discard >= 0 && discard + k <= nc,
+                  "topk_rows: need 0 < k and discard + k <= cohort size (k=%d discard=%d nc=%d)", k,
+                  discard, nc);
+    HYPMI_REQUIRE(n_rows <= 0x7fffffffLL, "topk_rows: too many rows");
+    if (n_rows == 0) return HYPMI_OK;
+    const int64_t lds_need = (272 + (int64_t)nc) * 4;
+    if (lds_need <= MAX_LDS_BYTES) {
+        if (lds_need > 48 * 1024)
+            HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_rows_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
+        hipLaunchKernelGGL(topk_rows_kernel<true>, dim3((unsigned)n_rows), dim3(TK_THREADS), lds_need,
+                           stream, A, lda, nc, k, discard, idx_t, ldi, (unsigned*)nullptr);
+    } else {
+        HYPMI_REQUIRE(workspace && workspace_bytes >= n_rows * (int64_t)nc * 4,
+                      "topk_rows: cohort of %d needs a %lld-byte workspace", nc,
+                      (long long)(n_rows * (int64_t)nc * 4));
+        hipLaunchKernelGGL(topk_rows_kernel<false>, dim3((unsigned)n_rows), dim3(TK_THREADS), 272 * 4,
+                           stream, A, lda, nc, k, discard, idx_t, ldi, static_cast<unsigned*>(workspace));
+    }
+    HYPMI_HIP(hipGetLastError());
+    return HYPMI_OK;
+}
+
+extern "C" int hypmi_gather_stats(const float* X, int64_t n_rows, int nc, int64_t ldx,
+                                  const unsigned char* mask, int64_t ldm, const int32_t* idx_t,
+                                  int64_t ldi, int k, int64_t n_lists, float std_floor, float* mean,
+                                  float* istd, int64_t ldo, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HYPMI_REQUIRE(X && idx_t && mean && istd, "gather_stats: null pointer");
+    HYPMI_REQUIRE(n_rows >= 0 && nc > 0 && ldx >= nc && k > 0 && n_lists >= 0 && ldi >= n_lists &&
+                      ldo >= n_lists,
+                  "gather_stats: bad shape");
+    HYPMI_REQUIRE(n_rows <= 0x7fffffffLL, "gather_stats: too many rows");
+    if (n_rows == 0 || n_lists == 0) return HYPMI_OK;
+    const int64_t lds_need = round_up((int64_t)nc * 4 + (mask ? nc : 0), 16);
+    HYPMI_REQUIRE(lds_need <= MAX_LDS_BYTES, "gather_stats: cohort of %d does not fit in LDS", nc);
+    if (lds_need > 48 * 1024)
+        HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_stats_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
+    // split the lists over blockIdx.y when there are few rows, so that the chip stays full
+    int64_t chunks = 1;
+    while (n_rows * chunks < 2048 && (n_lists + chunks - 1) / chunks > 4096) chunks *= 2;
+    if (chunks > 65535) chunks = 65535;
+    const int64_t q_per_block = round_up((n_lists + chunks - 1) / chunks, 256);
+    chunks = (n_lists + q_per_block - 1) / q_per_block;
+    hipLaunchKernelGGL(gather_stats_kernel, dim3((unsigned)n_rows, (unsigned)chunks), dim3(256), lds_need,
+                       stream, X, ldx, mask, ldm, nc, idx_t, ldi, k, n_lists, q_per_block, std_floor,
+                       mean, istd, ldo);
+    HYPMI_HIP(hipGetLastError());
+    return HYPMI_OK;
+}
+
+extern "C" int hypmi_asnorm_apply(const float* S, int64_t lds_, int64_t ne, int64_t nt, const float* mz,
+                                  const float* iz, int64_t ldz, const float* mt, const float* it,
+                                  int64_t ldt, float* out, int64_t ldo, void* stream_) {
+    HYPMI_REQUIRE(S && mz && iz && mt && it && out, "asnorm_apply: null pointer");
+    HYPMI_REQUIRE(ne >= 0 && nt >= 0 && lds_ >= nt && ldz >= nt && ldt >= ne && ldo >= nt,
+                  "asnorm_apply: bad shape");
+    if (ne == 0 || nt == 0) return HYPMI_OK;
+    const int64_t gy = (ne + 31) / 32, gx = (nt + 31) / 32;
+    HYPMI_REQUIRE(gy <= 65535, "asnorm_apply: more than 2M enrol rows per call");
+    hipLaunchKernelGGL(asnorm_apply_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), S, lds_, ne, nt, mz, iz, ldz, mt, it, ldt, out,
+                       ldo);
+    HYPMI_HIP(hipGetLastError());
+    return HYPMI_OK;
+}
+
+extern "C" int hypmi_transpose(const float* in, int64_t rows, int64_t cols, int64_t ldi, float* out,
+                               int64_t ldo, void* stream_) {
+    HYPMI_REQUIRE(in && out && rows >= 0 && cols >= 0 && ldi >= cols && ldo >= rows,
+                  "transpose: bad argument");
+    if (rows == 0 || cols == 0) return HYPMI_OK;
+    const int64_t gy = (rows + 31) / 32, gx = (cols + 31) / 32;
+    HYPMI_REQUIRE(gy <= 65535, "transpose: more than 2M rows per call");
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), in, ldi, rows, cols, out, ldo);
+    HYPMI_HIP(hipGetLastError());
+    return HYPMI_OK;
+}
+
+extern "C" int hypmi_row_meanstd(const float* X, int64_t n_rows, int nc, int64_t ldx,
+                                 const unsigned char* mask, int64_t ldm, float std_floor, float* mean,
+                                 float* istd, void* stream_) {
+    HYPMI_REQUIRE(X && mean && istd && n_rows >= 0 && nc > 0 && ldx >= nc, "row_meanstd: bad argument");
+    if (n_rows == 0) return HYPMI_OK;
+    hipLaunchKernelGGL(row_meanstd_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), X, ldx, n_rows, nc, mask, ldm, std_floor, mean,
+                       istd);
+    HYPMI_HIP(hipGetLastError());
+    return HYPMI_OK;
+}
+
+extern "C" int hypmi_norm_apply(const float* S, int64_t lds_, int64_t ne, int64_t nt, const float* mz,
+                                const float* iz, const float* mt, const float* it, float* out,
+                                int64_t ldo, void* stream_) {
+    HYPMI_REQUIRE(S && out && ne >= 0 && nt >= 0 && lds_ >= nt && ldo >= nt, "norm_apply: bad argument");
+    HYPMI_REQUIRE((mz == nullptr) == (iz == nullptr) && (mt == nullptr) == (it == nullptr) && (mz || mt),
+                  "norm_apply: statistics must come in (mean, 1/std) pairs");
+    if (ne == 0 || nt == 0) return HYPMI_OK;
+    for (int64_t e0 = 0; e0 < ne; e0 += 65535) {
+        const int64_t rows = ne - e0 < 65535 ? ne - e0 : 65535;
+        hipLaunchKernelGGL(norm_apply_kernel, dim3((unsigned)((nt + 255) / 256), (unsigned)rows), dim3(256),
+                           0, static_cast<hipStream_t>(stream_), S + e0 * lds_, lds_, rows, nt,
+                           mz ? mz + e0 : nullptr, iz ? iz + e0 : nullptr, mt, it, out + e0 * ldo, ldo);
+    }
+    HYPMI_HIP(hipGetLastError());
+    return HYPMI_OK;
+}
+
+extern "C" int hypmi_mask_zero(float* X, int64_t rows, int64_t cols, int64_t ldx, const unsigned char* mask,
+                               int64_t ldm, void* stream_) {
+    HYPMI_REQUIRE(X && mask && rows >= 0 && cols >= 0 && ldx >= cols && ldm >= cols,
+                  "mask_zero: bad argument");
+    if (rows == 0 || cols == 0) return HYPMI_OK;
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+        const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+        hipLaunchKernelGGL(mask_zero_kernel, dim3((unsigned)((cols + 255) / 256), (unsigned)nr), dim3(256), 0,
+                           static_cast<hipStream_t>(stream_), X + r0 * ldx, ldx, nr, cols, mask + r0 * ldm,
+                           ldm);
+    }
+    HYPMI_HIP(hipGetLastError());
+    return HYPMI_OK;
+}

@@ -1,0 +1,356 @@
+// Plans (device-resident folded models) and the embedding prologue:
+//   x -> [affine (+ length norm)]* -> (g, h) = y [At | An] + [bt | bn] -> packed row
+//   [g, q, 1] or [g, 1, q + c],  q = (|g|^2 - |h|^2) / 2.
+// The affine steps run on the matrix cores (gemm_nt.hip); the row-wise steps are one wavefront per
+// embedding with fp64 wave reductions (the norms and q feed every score of that row, so they are
+// accumulated in double even though the data is fp32).
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+void hypmi_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* hypmi_last_error(void) { return g_err; }
+extern "C" int hypmi_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------ plan
+struct Segment {
+    float* Wt = nullptr;   // [d_out x ldw] transposed weight, zero padded (nullptr = identity)
+    float* bias = nullptr; // [d_out] or nullptr
+    int64_t ldw = 0;
+    int d_in = 0, d_out = 0;
+    bool lnorm = false;
+};
+
+struct hypmi_plan {
+    int d_in = 0, n_seg = 0, d_last = 0, K = 0, KP = 0;
+    Segment seg[HYPMI_MAX_SEG];
+    Segment fin;  // [At | An]^T, 2K outputs
+    double c = 0.0;
+    int max_dim = 0;
+};
+
+namespace {
+
+int upload_transposed(const double* A, int d_in, int d_out, float** out, int64_t* ldw) {
+    // A is [d_in x d_out] row-major on the host; device copy is [d_out x ld] fp32, ld = d_in up to 4
+    const int64_t ld = round_up(d_in, 4);
+    std::vector<float> tmp((size_t)d_out * ld, 0.f);
+    for (int i = 0; i < d_in; ++i)
+        for (int j = 0; j < d_out; ++j) tmp[(size_t)j * ld + i] = (float)A[(size_t)i * d_out + j];
+    float* dev = nullptr;
+    if (hipMalloc(&dev, tmp.size() * sizeof(float)) != hipSuccess) {
+        hypmi_set_error("plan: device allocation of %zu bytes failed", tmp.size() * sizeof(float));
+        return HYPMI_ENOMEM;
+    }
+    HYPMI_HIP(hipMemcpy(dev, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice));
+    *out = dev;
+    *ldw = ld;
+    return HYPMI_OK;
+}
+
+int upload_vec(const double* b, int n, float** out) {
+    std::vector<float> tmp(n);
+    for (int i = 0; i < n; ++i) tmp[i] = (float)b[i];
+    float* dev = nullptr;
+    if (hipMalloc(&dev, n * sizeof(float)) != hipSuccess) {
+        hypmi_set_error("plan: device allocation failed");
+        return HYPMI_ENOMEM;
+    }
+    HYPMI_HIP(hipMemcpy(dev, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    *out = dev;
+    return HYPMI_OK;
+}
+
+}  // namespace
+
+extern "C" void hypmi_plan_destroy(hypmi_plan* p) {
+    if (!p) return;
+    for (int i = 0; i < HYPMI_MAX_SEG; ++i) {
+        if (p->seg[i].Wt) (void)hipFree(p->seg[i].Wt);
+        if (p->seg[i].bias) (void)hipFree(p->seg[i].bias);
+    }
+    if (p->fin.Wt) (void)hipFree(p->fin.Wt);
+    if (p->fin.bias) (void)hipFree(p->fin.bias);
+    delete p;
+}
+
+extern "C" int hypmi_plan_create(const hypmi_plan_desc* d, hypmi_plan** out) {
+    HYPMI_REQUIRE(d && out, "plan_create: null argument");
+    HYPMI_REQUIRE(d->d_in > 0, "plan_create: d_in must be positive");
+    HYPMI_REQUIRE(d->n_seg >= 0 && d->n_seg <= HYPMI_MAX_SEG, "plan_create: n_seg out of range");
+    HYPMI_REQUIRE(d->K >= 0, "plan_create: negative K");
+    HYPMI_REQUIRE(d->K == 0 || (d->At && d->An), "plan_create: At/An required when K > 0");
+    hypmi_plan* p = new hypmi_plan();
+    p->d_in = d->d_in;
+    p->n_seg = d->n_seg;
+    p->K = d->K;
+    p->c = d->c;
+    p->max_dim = d->d_in;
+    int cur = d->d_in;
+    int rc = HYPMI_OK;
+    for (int i = 0; i < d->n_seg && rc == HYPMI_OK; ++i) {
+        const hypmi_segment& s = d->seg[i];
+        Segment& t = p->seg[i];
+        t.d_in = cur;
+        t.d_out = s.d_out;
+        t.lnorm = s.lnorm != 0;
+        if (s.d_out <= 0 || (!s.A && s.d_out != cur)) {
+            hypmi_set_error("plan_create: segment %d has d_out=%d for d_in=%d", i, s.d_out, cur);
+            rc = HYPMI_EINVAL;
+            break;
+        }
+        if (s.A) {
+            rc = upload_transposed(s.A, cur, s.d_out, &t.Wt, &t.ldw);
+            if (rc == HYPMI_OK && s.b) rc = upload_vec(s.b, s.d_out, &t.bias);
+        } else if (s.b) {
+            // bias without a matrix: identity weight keeps one code path
+            std::vector<double> I((size_t)cur * cur, 0.0);
+            for (int k = 0; k < cur; ++k) I[(size_t)k * cur + k] = 1.0;
+            rc = upload_transposed(I.data(), cur, cur, &t.Wt, &t.ldw);
+            if (rc == HYPMI_OK) rc = upload_vec(s.b, s.d_out, &t.bias);
+        }
+        cur = s.d_out;
+        if (cur > p->max_dim) p->max_dim = cur;
+    }
+    p->d_last = cur;
+    if (rc == HYPMI_OK && d->K > 0) {
+        const int K = d->K;
+        std::vector<double> W((size_t)cur * 2 * K), b(2 * K, 0.0);
+        for (int i = 0; i < cur; ++i)
+            for (int j = 0; j < K; ++j) {
+                W[(size_t)i * 2 * K + j] = d->At[(size_t)i * K + j];
+                W[(size_t)i * 2 * K + K + j] = d->An[(size_t)i * K + j];
+            }
+        for (int j = 0; j < K; ++j) {
+            if (d->bt) b[j] = d->bt[j];
+            if (d->bn) b[K + j] = d->bn[j];
+        }
+        p->fin.d_in = cur;
+        p->fin.d_out = 2 * K;
+        rc = upload_transposed(W.data(), cur, 2 * K, &p->fin.Wt, &p->fin.ldw);
+        if (rc == HYPMI_OK) rc = upload_vec(b.data(), 2 * K, &p->fin.bias);
+        p->KP = hypmi_kp_for_k(K);
+    }
+    if (rc != HYPMI_OK) {
+        hypmi_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return HYPMI_OK;
+}
+
+extern "C" int hypmi_plan_kp(const hypmi_plan* p) { return p ? p->KP : 0; }
+extern "C" int hypmi_plan_k(const hypmi_plan* p) { return p ? p->K : 0; }
+extern "C" int hypmi_plan_d_in(const hypmi_plan* p) { return p ? p->d_in : 0; }
+extern "C" int hypmi_plan_d_out(const hypmi_plan* p) { return p ? p->d_last : 0; }
+
+// ------------------------------------------------------------------------------------ kernels
+namespace {
+
+constexpr int64_t CHUNK_ROWS = 65536;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// one wavefront per row: y <- sqrt(d) y / (|y| + 1e-10)
+__global__ __launch_bounds__(256) void lnorm_rows_kernel(float* __restrict__ y, int64_t n, int64_t ldy,
+                                                         int d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float* p = y + row * ldy;
+    double ss = 0.0;
+    for (int k = lane; k < d; k += 64) {
+        const double v = p[k];
+        ss += v * v;
+    }
+    ss = wave_sum(ss);
+    const float scale = (float)(sqrt((double)d) / (sqrt(ss) + 1e-10));
+    for (int k = lane; k < d; k += 64) p[k] *= scale;
+}
+
+// one wavefront per row: Z = [g | h] (2K floats) -> packed row of width KP
+__global__ __launch_bounds__(256) void pack_gq_kernel(const float* __restrict__ Z, int64_t n, int64_t ldz,
+                                                      int K, int KP, int side, double c,
+                                                      float* __restrict__ G) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* z = Z + row * ldz;
+    float* g = G + row * KP;
+    double sg = 0.0, sh = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        const float gv = z[k];
+        const double hv = z[K + k];
+        sg += (double)gv * gv;
+        sh += hv * hv;
+        g[k] = gv;
+    }
+    const double q = 0.5 * (wave_sum(sg) - wave_sum(sh));
+    for (int k = K + lane; k < KP; k += 64) {
+        float v = 0.f;
+        if (k == K) v = side == HYPMI_SIDE_ENROL ? (float)q : 1.f;
+        if (k == K + 1) v = side == HYPMI_SIDE_ENROL ? 1.f : (float)(q + c);
+        g[k] = v;
+    }
+}
+
+int run_lnorm(float* y, int64_t n, int64_t ldy, int d, hipStream_t stream) {
+    if (n == 0) return HYPMI_OK;
+    hipLaunchKernelGGL(lnorm_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, y, n, ldy, d);
+    HYPMI_HIP(hipGetLastError());
+    return HYPMI_OK;
+}
+
+struct Work {
+    float* buf[2];
+    float* z;
+    int64_t ld, ldz, rows;
+};
+
+int carve(const hypmi_plan* p, int64_t n, void* ws, int64_t ws_bytes, Work* w) {
+    const int64_t need = hypmi_prologue_workspace_bytes(p, n);
+    HYPMI_REQUIRE(need == 0 || (ws && aligned16(ws)), "workspace must be a 16-byte aligned device pointer");
+    HYPMI_REQUIRE(ws_bytes >= need, "workspace too small: %lld < %lld bytes", (long long)ws_bytes,
+                  (long long)need);
+    w->rows = n < CHUNK_ROWS ? n : CHUNK_ROWS;
+    w->ld = round_up(p->max_dim, 4);
+    w->ldz = round_up(2 * p->K, 4);
+    float* base = static_cast<float*>(ws);
+    w->buf[0] = base;
+    w->buf[1] = base + w->rows * w->ld;
+    w->z = base + 2 * w->rows * w->ld;
+    return HYPMI_OK;
+}
+
+// Runs the segments on `rows` rows starting at x.  On return *cur / *ldcur describe where the result
+// lives (x itself when the chain is empty).  If `final_out` is given, the last materialising step
+// writes straight into it.
+int run_segments(const hypmi_plan* p, const float* x, int64_t ldx, int64_t rows, const Work& w,
+                 float* final_out, int64_t ld_final, const float** cur, int64_t* ldcur,
+                 hipStream_t stream) {
+    const float* in = x;
+    int64_t ldin = ldx;
+    int which = 0;
+    int last_mat = -1;  // last segment that has to write a buffer
+    for (int i = 0; i < p->n_seg; ++i)
+        if (p->seg[i].Wt || p->seg[i].lnorm) last_mat = i;
+    for (int i = 0; i < p->n_seg; ++i) {
+        const Segment& s = p->seg[i];
+        if (!s.Wt && !s.lnorm) continue;
+        const bool to_final = final_out && i == last_mat;
+        float* dst = nullptr;
+        int64_t lddst = 0;
+        if (s.Wt) {
+            dst = to_final ? final_out : w.buf[which];
+            lddst = to_final ? ld_final : w.ld;
+            int rc = hypmi_launch_gemm_nt(in, ldin, s.Wt, s.ldw, s.bias, dst, lddst, rows, s.d_out,
+                                          s.d_in, stream);
+            if (rc != HYPMI_OK) return rc;
+        } else if (in == x || to_final) {
+            // length norm only: never touch the caller's input, normalise a copy
+            dst = to_final ? final_out : w.buf[which];
+            lddst = to_final ? ld_final : w.ld;
+            HYPMI_HIP(hipMemcpy2DAsync(dst, lddst * sizeof(float), in, ldin * sizeof(float),
+                                       (size_t)s.d_in * sizeof(float), (size_t)rows,
+                                       hipMemcpyDeviceToDevice, stream));
+        } else {
+            dst = const_cast<float*>(in);  // already one of our scratch buffers
+            lddst = ldin;
+        }
+        if (s.lnorm) {
+            int rc = run_lnorm(dst, rows, lddst, s.d_out, stream);
+            if (rc != HYPMI_OK) return rc;
+        }
+        if (dst == w.buf[which]) which ^= 1;
+        in = dst;
+        ldin = lddst;
+    }
+    *cur = in;
+    *ldcur = ldin;
+    return HYPMI_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t hypmi_prologue_workspace_bytes(const hypmi_plan* p, int64_t n) {
+    if (!p || n <= 0) return 0;
+    const int64_t rows = n < CHUNK_ROWS ? n : CHUNK_ROWS;
+    const int64_t ld = round_up(p->max_dim, 4);
+    const int64_t ldz = round_up(2 * p->K, 4);
+    return rows * (2 * ld + ldz) * (int64_t)sizeof(float);
+}
+
+extern "C" int hypmi_lnorm_rows(float* y, int64_t n, int64_t ldy, int d, void* stream) {
+    HYPMI_REQUIRE(y && n >= 0 && d > 0 && ldy >= d, "lnorm_rows: bad argument");
+    return run_lnorm(y, n, ldy, d, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int hypmi_prologue(const hypmi_plan* p, const float* x, int64_t n, int64_t ldx, int side,
+                              float* G, void* ws, int64_t ws_bytes, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HYPMI_REQUIRE(p && p->K > 0, "prologue: plan has no PLDA projection");
+    HYPMI_REQUIRE(x && G, "prologue: null pointer");
+    HYPMI_REQUIRE(n >= 0 && ldx >= round_up(p->d_in, 4) && ldx % 4 == 0 && aligned16(x),
+                  "prologue: x must be 16-byte aligned with ldx %% 4 == 0 and ldx >= d_in rounded up to 4");
+    HYPMI_REQUIRE(side == HYPMI_SIDE_ENROL || side == HYPMI_SIDE_TEST, "prologue: bad side %d", side);
+    if (n == 0) return HYPMI_OK;
+    Work w;
+    int rc = carve(p, n, ws, ws_bytes, &w);
+    if (rc != HYPMI_OK) return rc;
+    for (int64_t r0 = 0; r0 < n; r0 += w.rows) {
+        const int64_t rows = (n - r0 < w.rows) ? n - r0 : w.rows;
+        const float* cur;
+        int64_t ldcur;
+        rc = run_segments(p, x + r0 * ldx, ldx, rows, w, nullptr, 0, &cur, &ldcur, stream);
+        if (rc != HYPMI_OK) return rc;
+        rc = hypmi_launch_gemm_nt(cur, ldcur, p->fin.Wt, p->fin.ldw, p->fin.bias, w.z, w.ldz, rows,
+                                  2 * p->K, p->fin.d_in, stream);
+        if (rc != HYPMI_OK) return rc;
+        hipLaunchKernelGGL(pack_gq_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, w.z,
+                           rows, w.ldz, p->K, p->KP, side, p->c, G + r0 * p->KP);
+        HYPMI_HIP(hipGetLastError());
+    }
+    return HYPMI_OK;
+}
+
+extern "C" int hypmi_transform(const hypmi_plan* p, const float* x, int64_t n, int64_t ldx, float* y,
+                               int64_t ldy, void* ws, int64_t ws_bytes, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HYPMI_REQUIRE(p && x && y, "transform: null pointer");
+    HYPMI_REQUIRE(n >= 0 && ldx >= round_up(p->d_in, 4) && ldx % 4 == 0 && aligned16(x),
+                  "transform: x must be 16-byte aligned with ldx %% 4 == 0");
+    HYPMI_REQUIRE(ldy >= p->d_last, "transform: ldy too small");
+    if (n == 0) return HYPMI_OK;
+    Work w;
+    int rc = carve(p, n, ws, ws_bytes, &w);
+    if (rc != HYPMI_OK) return rc;
+    for (int64_t r0 = 0; r0 < n; r0 += w.rows) {
+        const int64_t rows = (n - r0 < w.rows) ? n - r0 : w.rows;
+        const float* cur;
+        int64_t ldcur;
+        rc = run_segments(p, x + r0 * ldx, ldx, rows, w, y + r0 * ldy, ldy, &cur, &ldcur, stream);
+        if (rc != HYPMI_OK) return rc;
+        if (cur != y + r0 * ldy) {  // empty chain: plain copy
+            HYPMI_HIP(hipMemcpy2DAsync(y + r0 * ldy, ldy * sizeof(float), cur, ldcur * sizeof(float),
+                                       (size_t)p->d_last * sizeof(float), (size_t)rows,
+                                       hipMemcpyDeviceToDevice, stream));
+        }
+    }
+    return HYPMI_OK;
+}

@@ -1,0 +1,204 @@
+"""Device engine: thin Python over the hypmi C ABI.  torch provides device memory and streams only;
+all arithmetic on embeddings and scores happens in the HIP kernels of libhypmi.so."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import SIDE_ENROL, SIDE_TEST  # noqa: F401
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def require_gpu():
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "hyperion_amd needs a HIP device (built for gfx950 / MI355X); there is no CPU fallback")
+    return torch
+
+
+def stream_ptr():
+    return ctypes.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def upload(x, dtype=None):
+    """numpy [n, d] (any float) -> device fp32 [n, ld] with ld = d rounded up to 4, pad zero.
+    A torch tensor already on the device is passed through after the same layout checks."""
+    torch = require_gpu()
+    if isinstance(x, torch.Tensor):
+        t = x
+        if t.device.type != "cuda":
+            t = t.cuda()
+        if t.dtype != torch.float32:
+            t = t.float()
+        if t.dim() != 2:
+            raise ValueError("expected a 2-D array of embeddings")
+        if t.stride(1) != 1 or t.stride(0) % 4 != 0 or t.data_ptr() % 16 != 0 or \
+                t.stride(0) < round_up(t.shape[1], 4):
+            n, d = t.shape
+            buf = torch.zeros((n, round_up(d, 4)), dtype=torch.float32, device=t.device)
+            buf[:, :d] = t
+            t = buf[:, :d]
+        return t
+    x = np.asarray(x)
+    if x.ndim != 2:
+        raise ValueError("expected a 2-D array of embeddings, got shape %s" % (x.shape,))
+    n, d = x.shape
+    host = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+    ld = round_up(d, 4)
+    if ld == d:
+        return host.cuda()
+    buf = torch.zeros((n, ld), dtype=torch.float32, device="cuda")
+    buf[:, :d] = host.cuda()
+    return buf[:, :d]
+
+
+def _as_c(a):
+    """float64 C-contiguous copy + ctypes pointer (None stays NULL)."""
+    if a is None:
+        return None, ctypes.cast(None, _lib.c_double_p)
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_lib.c_double_p)
+
+
+class Plan:
+    """Device-resident folded model (hypmi_plan).  `segments` is a list of (A, b, d_out) affine
+    maps each followed by a length normalisation; `tail` = (A, b) is applied after the last
+    normalisation; `proj` = (At, bt, An, bn, c) is the PLDA projection (None for a
+    transform-only plan, in which case the tail becomes a final un-normalised segment)."""
+
+    def __init__(self, d_in, segments=(), tail=(None, None), proj=None):
+        require_gpu()
+        lib = _lib.load()
+        from .fold import compose
+
+        keep = []
+        desc = _lib.PlanDesc()
+        desc.d_in = int(d_in)
+        segs = [(A, b, d, 1) for (A, b, d) in segments]
+        d_last = segs[-1][2] if segs else d_in
+        if proj is None:
+            A, b = tail
+            if A is not None or b is not None:
+                d_last = A.shape[1] if A is not None else d_last
+                segs.append((A, b, d_last, 0))
+            desc.K = 0
+        else:
+            At, bt, An, bn, c = proj
+            (At2, bt2) = compose(tail, (At, bt))
+            (An2, bn2) = compose(tail, (An, bn))
+            a, desc.At = _as_c(At2)
+            keep.append(a)
+            a, desc.bt = _as_c(bt2)
+            keep.append(a)
+            a, desc.An = _as_c(An2)
+            keep.append(a)
+            a, desc.bn = _as_c(bn2)
+            keep.append(a)
+            desc.K = int(At2.shape[1])
+            desc.c = float(c)
+            if At2.shape[0] != d_last:
+                raise ValueError("PLDA model expects %d-dim vectors, pre-processing gives %d"
+                                 % (At2.shape[0], d_last))
+        if len(segs) > _lib.HYPMI_MAX_SEG:
+            raise ValueError("at most %d length-normalised segments are supported" % _lib.HYPMI_MAX_SEG)
+        desc.n_seg = len(segs)
+        for i, (A, b, d, ln) in enumerate(segs):
+            a, desc.seg[i].A = _as_c(A)
+            keep.append(a)
+            a, desc.seg[i].b = _as_c(b)
+            keep.append(a)
+            desc.seg[i].d_out = int(d)
+            desc.seg[i].lnorm = int(ln)
+        handle = ctypes.c_void_p()
+        _lib.check(lib.hypmi_plan_create(ctypes.byref(desc), ctypes.byref(handle)))
+        self._h = handle
+        self._lib = lib
+        self.kp = lib.hypmi_plan_kp(handle)
+        self.k = lib.hypmi_plan_k(handle)
+        self.d_in = lib.hypmi_plan_d_in(handle)
+        self.d_out = lib.hypmi_plan_d_out(handle)
+        self.c = float(proj[4]) if proj is not None else 0.0
+        del keep
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                self._lib.hypmi_plan_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def _workspace(self, n):
+        torch = _torch()
+        nbytes = self._lib.hypmi_prologue_workspace_bytes(self._h, n)
+        return torch.empty((max(nbytes, 16) + 3) // 4, dtype=torch.float32, device="cuda"), nbytes
+
+    def _check_x(self, x):
+        if x.shape[1] != self.d_in:
+            raise ValueError("expected %d-dim embeddings, got %d" % (self.d_in, x.shape[1]))
+
+    def prologue(self, x, side):
+        """x: device fp32 [n, d_in] (see upload) -> packed rows [n, kp]."""
+        torch = _torch()
+        self._check_x(x)
+        n = x.shape[0]
+        G = torch.empty((n, self.kp), dtype=torch.float32, device=x.device)
+        if n == 0:
+            return G
+        ws, nbytes = self._workspace(n)
+        _lib.check(self._lib.hypmi_prologue(self._h, _ptr(x), n, x.stride(0), int(side), _ptr(G),
+                                            _ptr(ws), nbytes, stream_ptr()))
+        return G
+
+    def transform(self, x):
+        """x: device fp32 [n, d_in] -> device fp32 [n, d_out] (pre-processing chain only)."""
+        torch = _torch()
+        self._check_x(x)
+        n = x.shape[0]
+        ld = round_up(self.d_out, 4)
+        y = torch.empty((n, ld), dtype=torch.float32, device=x.device)
+        if ld != self.d_out:
+            y.zero_()
+        if n:
+            ws, nbytes = self._workspace(n)
+            _lib.check(self._lib.hypmi_transform(self._h, _ptr(x), n, x.stride(0), _ptr(y), ld,
+                                                 _ptr(ws), nbytes, stream_ptr()))
+        return y[:, :self.d_out]
+
+
+def score(G1, G2, out=None):
+    """Packed enrol rows x packed test rows -> device fp32 score matrix [n1, n2]."""
+    torch = _torch()
+    lib = _lib.load()
+    n1, kp = G1.shape
+    n2, kp2 = G2.shape
+    if kp != kp2:
+        raise ValueError("packed widths differ: %d vs %d" % (kp, kp2))
+    if out is None:
+        ld = round_up(max(n2, 1), 32)  # full 128-byte lines per stored row segment
+        buf = torch.empty((n1, ld), dtype=torch.float32, device=G1.device)
+        out = buf[:, :n2]
+    if n1 and n2:
+        _lib.check(lib.hypmi_score(_ptr(G1), n1, _ptr(G2), n2, kp, _ptr(out), out.stride(0),
+                                   stream_ptr()))
+    return out
+
+
+def to_host(t, dtype):
+    """Device tensor -> numpy array of the host float type."""
+    return t.cpu().numpy().astype(dtype, copy=False)

@@ -1,0 +1,30 @@
+"""Global float types of the host API (same contract as hyperion/hyp_defs.py:9-38): results handed
+back to numpy callers are `float_cpu()` arrays (float64 unless changed), while the device path
+computes in fp32 on the MI355X matrix cores."""
+import numpy as np
+
+_FLOAT_CPU = "float64"
+_FLOAT_SAVE = "float32"
+
+
+def float_cpu():
+    return _FLOAT_CPU
+
+
+def set_float_cpu(float_cpu):
+    global _FLOAT_CPU
+    _FLOAT_CPU = float_cpu
+
+
+def float_save():
+    return _FLOAT_SAVE
+
+
+def set_float_save(float_save):
+    global _FLOAT_SAVE
+    _FLOAT_SAVE = float_save
+
+
+def float_device():
+    """Arithmetic type of the HIP kernels."""
+    return np.float32

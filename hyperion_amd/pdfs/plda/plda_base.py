@@ -1,0 +1,273 @@
+"""Common scoring machinery of the PLDA models (host API of hyperion/pdfs/plda/plda_base.py,
+executed on the GPU).  Training (fit / E-step / M-step) is outside this package."""
+import numpy as np
+
+from ... import _lib, engine
+from ...engine import SIDE_ENROL, SIDE_TEST
+from ...fold import fold_chain
+from ...hyp_defs import float_cpu
+from ...hyp_model import HypModel, fingerprint
+
+_LNORM_STEP = (None, None, True)  # parameter-free length normalisation, LNorm()
+
+
+def _group_index(class_ids):
+    """Row order grouped by class and group offsets for classes 0..max(id)
+    (plda_base.py:251: num_classes = max(class_ids) + 1; ids that never occur give empty groups)."""
+    ids = np.asarray(class_ids)
+    if ids.ndim != 1:
+        raise ValueError("class ids must be a 1-D integer array")
+    ids = ids.astype(np.int64)
+    if ids.size and ids.min() < 0:
+        raise ValueError("class ids must be non-negative")
+    num_classes = int(ids.max()) + 1 if ids.size else 0
+    order = np.argsort(ids, kind="stable").astype(np.int32)
+    counts = np.bincount(ids, minlength=num_classes)
+    offsets = np.zeros(num_classes + 1, dtype=np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    return order, offsets, counts
+
+
+def pool_rows(x_dev, class_ids, mean):
+    """Device class pooling.  x_dev: device fp32 [n, d].  Returns (pooled [C, d] device tensor,
+    counts as a host int array)."""
+    torch = engine.require_gpu()
+    lib = _lib.load()
+    order, offsets, counts = _group_index(class_ids)
+    if order.shape[0] != x_dev.shape[0]:
+        raise ValueError("%d class ids for %d rows" % (order.shape[0], x_dev.shape[0]))
+    C, d = len(counts), x_dev.shape[1]
+    ld = engine.round_up(d, 4)
+    out = torch.zeros((C, ld), dtype=torch.float32, device=x_dev.device)
+    if C:
+        o_dev = torch.from_numpy(order).to(x_dev.device)
+        f_dev = torch.from_numpy(offsets).to(x_dev.device)
+        _lib.check(lib.hypmi_pool_rows(engine._ptr(x_dev), x_dev.stride(0), d, engine._ptr(o_dev),
+                                       engine._ptr(f_dev), C, int(bool(mean)), engine._ptr(out), ld,
+                                       None, engine.stream_ptr()))
+    return out[:, :d], counts
+
+
+class PLDABase(HypModel):
+    def __init__(self, y_dim=None, mu=None, update_mu=True, **kwargs):
+        super().__init__(**kwargs)
+        self.mu = mu
+        self.y_dim = y_dim
+        self.update_mu = update_mu
+        if mu is not None:
+            self.x_dim = mu.shape[0]
+        self._plans = {}
+
+    # ---- to be provided by the concrete model ---------------------------------------------
+    def _params(self):
+        raise NotImplementedError
+
+    def _fold(self):
+        """-> (At, bt, An, bn, c) in float64, see hyperion_amd/fold.py."""
+        raise NotImplementedError
+
+    def _book_fold(self):
+        """-> dict(P, row_bias, shift_t, shift_n, lam, c_extra), see llr_NvsM_book."""
+        raise NotImplementedError
+
+    def validate(self):
+        raise NotImplementedError
+
+    # ---- plans -----------------------------------------------------------------------------
+    def score_plan(self, preproc=None, lnorm_first=False):
+        """Device plan for [preproc chain ->] [LNorm() ->] this model's projection.  `preproc` is
+        a hyperion_amd TransformList (or a list of transforms) folded in front of the model."""
+        self.validate()
+        transforms = []
+        if preproc is not None:
+            transforms = list(getattr(preproc, "transforms", preproc))
+        key = (fingerprint(*self._params()), tuple(t._params_key() for t in transforms),
+               tuple(type(t).__name__ for t in transforms), bool(lnorm_first))
+        plan = self._plans.get(key)
+        if plan is None:
+            steps = [t._step() for t in transforms]
+            if lnorm_first:
+                steps.append(_LNORM_STEP)
+            d_in = self.x_dim
+            for A, b, _ in steps:  # input dim of the chain = first matrix's rows, else model dim
+                if A is not None:
+                    d_in = A.shape[0]
+                    break
+                if b is not None:
+                    d_in = b.shape[0]
+                    break
+            segments, tail, d_out = fold_chain(steps, d_in)
+            if d_out != self.x_dim:
+                raise ValueError("pre-processing gives %d-dim vectors, model expects %d"
+                                 % (d_out, self.x_dim))
+            if len(self._plans) > 8:
+                self._plans.clear()
+            plan = engine.Plan(d_in, segments, tail, self._fold())
+            self._plans[key] = plan
+        return plan
+
+    # ---- 1 vs 1 -----------------------------------------------------------------------------
+    def llr_1vs1(self, x1, x2, preproc=None):
+        """Log-likelihood ratio of every (x1[i], x2[j]) pair: [N1, N2] `float_cpu()` array.
+        numpy in / numpy out; device tensors in give a device tensor out."""
+        torch = engine.require_gpu()
+        plan = self.score_plan(preproc)
+        dev_out = isinstance(x1, torch.Tensor) and isinstance(x2, torch.Tensor)
+        G1 = plan.prologue(engine.upload(x1), SIDE_ENROL)
+        G2 = plan.prologue(engine.upload(x2), SIDE_TEST)
+        S = engine.score(G1, G2)
+        return S if dev_out else engine.to_host(S, float_cpu())
+
+    # ---- sufficient statistics ----------------------------------------------------------------
+    @staticmethod
+    def compute_stats_hard(x, class_ids, sample_weight=None, scale_factor=None):
+        """(N, F, S) per class for classes 0..max(id) (plda_base.py:249-274).  N and F are
+        computed on the GPU; the second-order statistic S is returned as None because no scoring
+        path reads it (training is outside this package)."""
+        if sample_weight is not None:
+            raise NotImplementedError("sample weights belong to training, which is not part of "
+                                      "the scoring path")
+        F_dev, counts = pool_rows(engine.upload(x), class_ids, mean=False)
+        N = counts.astype(float_cpu())
+        F = engine.to_host(F_dev, float_cpu())
+        if scale_factor is not None:
+            N = N * scale_factor
+            F = F * scale_factor
+        return N, F, None
+
+    # ---- N vs M -----------------------------------------------------------------------------
+    def _pooled_mean(self, x, ids):
+        """Device class means F / N; `x` may already be a statistics tuple (ids is None)."""
+        torch = engine.require_gpu()
+        if ids is None:
+            lib = _lib.load()
+            F = engine.upload(x[1]).clone()
+            N = torch.from_numpy(np.ascontiguousarray(x[0], dtype=np.float32)).to(F.device)
+            _lib.check(lib.hypmi_div_rows(engine._ptr(F), F.stride(0), F.shape[0], F.shape[1],
+                                          engine._ptr(N), engine.stream_ptr()))
+            return F
+        xm, _ = pool_rows(engine.upload(x), ids, mean=True)
+        return xm
+
+    def llr_NvsM(self, x1, x2, ids1=None, ids2=None, method="vavg-lnorm"):
+        if method == "savg":
+            return self._llr_savg(x1, ids1, x2, ids2)
+        if method == "book":
+            D1 = x1 if ids1 is None else self._stats_dev(x1, ids1)
+            D2 = x2 if ids2 is None else self._stats_dev(x2, ids2)
+            return self.llr_NvsM_book(D1, D2)
+        if method not in ("vavg", "vavg-lnorm"):
+            raise ValueError("unknown pooling method %r" % (method,))
+        plan = self.score_plan(lnorm_first=(method == "vavg-lnorm"))
+        G1 = plan.prologue(self._pooled_mean(x1, ids1), SIDE_ENROL)
+        G2 = plan.prologue(self._pooled_mean(x2, ids2), SIDE_TEST)
+        return engine.to_host(engine.score(G1, G2), float_cpu())
+
+    def llr_Nvs1(self, x1, x2, ids1=None, method="vavg-lnorm"):
+        if method == "savg":
+            return self._llr_savg(x1, ids1, x2, None)
+        if method == "book":
+            D1 = x1 if ids1 is None else self._stats_dev(x1, ids1)
+            D2 = self._stats_dev(x2, np.arange(np.asarray(x2).shape[0]))
+            return self.llr_NvsM_book(D1, D2)
+        if method not in ("vavg", "vavg-lnorm"):
+            raise ValueError("unknown pooling method %r" % (method,))
+        plan = self.score_plan(lnorm_first=(method == "vavg-lnorm"))
+        G1 = plan.prologue(self._pooled_mean(x1, ids1), SIDE_ENROL)
+        G2 = plan.prologue(engine.upload(x2), SIDE_TEST)
+        return engine.to_host(engine.score(G1, G2), float_cpu())
+
+    def _llr_savg(self, x1, ids1, x2, ids2):
+        """Score averaging (plda_base.py:316-322, 347-351).  The score is bilinear in the packed
+        rows, so averaging the segment-level scores over a class equals scoring the class mean of
+        the packed rows; the [segments x segments] matrix is never formed."""
+        plan = self.score_plan()
+        G1 = plan.prologue(engine.upload(x1), SIDE_ENROL)
+        G2 = plan.prologue(engine.upload(x2), SIDE_TEST)
+        if ids1 is not None:
+            G1 = pool_rows(G1, ids1, mean=True)[0].contiguous()
+        if ids2 is not None:
+            G2 = pool_rows(G2, ids2, mean=True)[0].contiguous()
+        return engine.to_host(engine.score(G1, G2), float_cpu())
+
+    def _stats_dev(self, x, ids):
+        F_dev, counts = pool_rows(engine.upload(x), ids, mean=False)
+        return counts.astype(np.float64), F_dev, None
+
+    def llr_NvsM_book(self, D1, D2):
+        """By-the-book multi-session scoring (splda.py:318-379, frplda.py:305-366,
+        plda.py:474-539) from statistics D = (N, F, S).
+
+        Every count n needs L(n) = I + n VV (or B + n W); instead of one Cholesky per count the
+        first-order statistics are projected once onto the eigen-basis that diagonalises all L(n)
+        and each (n1, n2) block only rescales that projection.  Unlike the reference, the
+        caller's F is not modified (the reference subtracts N mu from it in place)."""
+        torch = engine.require_gpu()
+        lib = _lib.load()
+        bf = self._book_fold()
+        K = bf["P"].shape[1]
+        kp = lib.hypmi_packed_width(K)
+        sides = []
+        for D in (D1, D2):
+            N = np.asarray(D[0], dtype=np.float64)
+            F = D[1]
+            F_dev = engine.upload(F)
+            n, d = F_dev.shape
+            # s = [F | N] [P ; row_bias]: one affine map with the class size as an extra input
+            ld = engine.round_up(d + 1, 4)
+            aug = torch.zeros((n, ld), dtype=torch.float32, device=F_dev.device)
+            aug[:, :d] = F_dev
+            aug[:, d] = torch.from_numpy(N.astype(np.float32)).to(F_dev.device)
+            Wt = np.zeros((K, ld), dtype=np.float32)
+            Wt[:, :d] = bf["P"].T
+            Wt[:, d] = bf["row_bias"]
+            Wt_dev = torch.from_numpy(Wt).to(F_dev.device)
+            lds_ = engine.round_up(K, 4)
+            s = torch.zeros((n, lds_), dtype=torch.float32, device=F_dev.device)
+            if n:
+                _lib.check(lib.hypmi_affine(engine._ptr(aug), n, ld, d + 1, engine._ptr(Wt_dev), ld,
+                                            None, K, engine._ptr(s), lds_, engine.stream_ptr()))
+            sides.append((N, s))
+        (N1, s1), (N2, s2) = sides
+        n1, n2 = len(N1), len(N2)
+        ldo = engine.round_up(max(n2, 1), 32)
+        out = torch.zeros((n1, ldo), dtype=torch.float32, device="cuda")
+        lam = bf["lam"]
+
+        def vec(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+        shift_t, shift_n = vec(bf["shift_t"]), vec(bf["shift_n"])
+        u1, u2 = np.unique(N1), np.unique(N2)
+        single = len(u1) == 1 and len(u2) == 1
+        for a in u1:
+            i = np.where(N1 == a)[0].astype(np.int32)
+            for b in u2:
+                j = np.where(N2 == b)[0].astype(np.int32)
+                sc_t = vec(1.0 / np.sqrt(1.0 + (a + b) * lam))
+                logL = lambda n: float(np.sum(np.log1p(n * lam)))  # noqa: E731
+                c = 0.5 * (logL(a) + logL(b) - logL(a + b)) + bf["c_extra"]
+                Gs = []
+                for (own, rows, s, side) in ((a, i, s1, SIDE_ENROL), (b, j, s2, SIDE_TEST)):
+                    sc_n = vec(1.0 / np.sqrt(1.0 + own * lam))
+                    G = torch.empty((len(rows), kp), dtype=torch.float32, device="cuda")
+                    r_dev = torch.from_numpy(rows).cuda()
+                    _lib.check(lib.hypmi_book_pack(engine._ptr(s), s.stride(0), K, engine._ptr(r_dev),
+                                                   len(rows), engine._ptr(shift_t), engine._ptr(sc_t),
+                                                   engine._ptr(shift_n), engine._ptr(sc_n), side, c,
+                                                   engine._ptr(G), kp, engine.stream_ptr()))
+                    Gs.append((G, r_dev))
+                if single:
+                    engine.score(Gs[0][0], Gs[1][0], out=out[:, :n2])
+                else:
+                    blk = engine.score(Gs[0][0], Gs[1][0])
+                    _lib.check(lib.hypmi_scatter_block(engine._ptr(blk), blk.stride(0),
+                                                       engine._ptr(Gs[0][1]), len(i),
+                                                       engine._ptr(Gs[1][1]), len(j), engine._ptr(out),
+                                                       ldo, engine.stream_ptr()))
+        return engine.to_host(out[:, :n2], float_cpu())
+
+    def get_config(self):
+        config = {"y_dim": self.y_dim, "update_mu": self.update_mu}
+        base_config = super().get_config()
+        return dict(list(base_config.items()) + list(config.items()))

@@ -1,0 +1,97 @@
+import numpy as np
+
+from .. import _lib, engine
+from ..hyp_defs import float_cpu
+from .score_norm import ScoreNorm, dev_mask, dev_matrix, transpose, transpose_mask, zero_masked
+
+
+def topk_rows(A, k, discard):
+    """Device [rows, cohort] -> int32 [k, rows] cohort indices ranked discard..discard+k-1 per row."""
+    torch = engine.require_gpu()
+    lib = _lib.load()
+    n, nc = A.shape
+    idx = torch.empty((k, max(n, 1)), dtype=torch.int32, device=A.device)
+    ws_bytes = lib.hypmi_topk_workspace_bytes(n, nc)
+    ws = torch.empty(max(ws_bytes // 4, 4), dtype=torch.int32, device=A.device)
+    _lib.check(lib.hypmi_topk_rows(engine._ptr(A), n, nc, A.stride(0), k, discard, engine._ptr(idx),
+                                   idx.stride(0), engine._ptr(ws), ws_bytes, engine.stream_ptr()))
+    return idx
+
+
+def gather_stats(X, mask_u8, idx, n_lists, std_floor):
+    """mean / inverse std of X[r, idx[:, q]] for every row r and list q: two device [rows, lists]."""
+    torch = engine.require_gpu()
+    lib = _lib.load()
+    n, nc = X.shape
+    ld = engine.round_up(max(n_lists, 1), 4)
+    mean = torch.empty((n, ld), dtype=torch.float32, device=X.device)
+    istd = torch.empty((n, ld), dtype=torch.float32, device=X.device)
+    _lib.check(lib.hypmi_gather_stats(engine._ptr(X), n, nc, X.stride(0),
+                                      engine._ptr(mask_u8) if mask_u8 is not None else None,
+                                      mask_u8.stride(0) if mask_u8 is not None else 0,
+                                      engine._ptr(idx), idx.stride(0), idx.shape[0], n_lists,
+                                      float(std_floor), engine._ptr(mean), engine._ptr(istd), ld,
+                                      engine.stream_ptr()))
+    return mean, istd, ld
+
+
+def adapt_s_norm_device(S, A_ec, A_tc, nbest, nbest_discard, mask_ec=None, mask_tc=None,
+                        std_floor=1e-5):
+    """Adaptive S-norm on device matrices: S [enrol, test], A_ec [enrol, cohort], A_tc [test, cohort]
+    (already zeroed where masked).  Returns a device [enrol, test] tensor."""
+    torch = engine.require_gpu()
+    lib = _lib.load()
+    ne, nt = S.shape
+    nc = A_ec.shape[1]
+    assert A_tc.shape[1] == nc and A_ec.shape[0] == ne and A_tc.shape[0] == nt
+    assert nbest_discard < nc
+    k = min(int(nbest), nc - int(nbest_discard))
+    ld = engine.round_up(max(nt, 1), 32)
+    out = torch.empty((ne, ld), dtype=torch.float32, device=S.device)
+    if ne == 0 or nt == 0:
+        return out[:, :nt]
+    t_idx = topk_rows(A_tc, k, int(nbest_discard))  # per test: cohort ranked by coh-vs-test
+    e_idx = topk_rows(A_ec, k, int(nbest_discard))  # per enrol: cohort ranked by enr-vs-coh
+    mz, iz, ldz = gather_stats(A_ec, mask_ec, t_idx, nt, std_floor)  # [enrol, test]
+    mt, it, ldt = gather_stats(A_tc, mask_tc, e_idx, ne, std_floor)  # [test, enrol]
+    _lib.check(lib.hypmi_asnorm_apply(engine._ptr(S), S.stride(0), ne, nt, engine._ptr(mz),
+                                      engine._ptr(iz), ldz, engine._ptr(mt), engine._ptr(it), ldt,
+                                      engine._ptr(out), ld, engine.stream_ptr()))
+    return out[:, :nt]
+
+
+class AdaptSNorm(ScoreNorm):
+    """Adaptive S-norm (hyperion/score_norm/adapt_s_norm.py:13-88): Z- and T-normalisation with
+    statistics over the `nbest` cohort members closest to each test / enrolment side, after
+    dropping the `nbest_discard` closest.  The std floor is the reference's literal 1e-5 (its
+    `std_floor` attribute is not consulted there either).  Caller arrays are never modified;
+    a tie exactly at the selection boundary goes to the lower cohort index (numpy's argsort leaves
+    it unspecified)."""
+
+    def __init__(self, nbest=100, nbest_discard=0, **kwargs):
+        super().__init__(**kwargs)
+        self.nbest = nbest
+        self.nbest_discard = nbest_discard
+
+    def predict(self, scores, scores_coh_test, scores_enr_coh, mask_coh_test=None, mask_enr_coh=None):
+        torch = engine.require_gpu()
+        S = dev_matrix(scores)
+        CT = dev_matrix(scores_coh_test)
+        EC = dev_matrix(scores_enr_coh)
+        assert EC.shape[1] == CT.shape[0]
+        assert self.nbest_discard < EC.shape[1]
+        assert EC.shape[0] == S.shape[0] and CT.shape[1] == S.shape[1]
+        m_ec = m_tc = None
+        if mask_coh_test is not None:
+            m_ct = dev_mask(mask_coh_test, CT.shape)
+            CT = CT.clone() if isinstance(scores_coh_test, torch.Tensor) else CT
+            zero_masked(CT, m_ct)
+            m_tc = transpose_mask(m_ct)
+        if mask_enr_coh is not None:
+            m_ec = dev_mask(mask_enr_coh, EC.shape)
+            EC = EC.clone() if isinstance(scores_enr_coh, torch.Tensor) else EC
+            zero_masked(EC, m_ec)
+        out = adapt_s_norm_device(S, EC, transpose(CT), self.nbest, self.nbest_discard, m_ec, m_tc)
+        if isinstance(scores, torch.Tensor):
+            return out
+        return engine.to_host(out, float_cpu())

@@ -1,0 +1,8 @@
+"""Embedding pre-processing with the hyperion.transforms call signatures, executed on the GPU."""
+from .cent_whiten import CentWhiten
+from .lnorm import LNorm
+from .lda import LDA
+from .pca import PCA
+from .transform_list import TransformList
+
+__all__ = ["CentWhiten", "LNorm", "LDA", "PCA", "TransformList"]

@@ -1,0 +1,190 @@
+/*
+ * hypmi — C ABI of the MI355X (gfx950) PLDA back-end scoring library.
+ *
+ * The reference is pure Python/numpy and has no FFI layer of its own; each entry point below names
+ * the numpy expression(s) of the reference it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative HYPMI_E* code; hypmi_last_error() gives a
+ *     thread-local message for the last failure on the calling thread;
+ *   - all data pointers are DEVICE pointers owned by the caller (the Python shim hands over
+ *     torch-allocated storage); the library owns only opaque hypmi_plan objects;
+ *   - all matrices are row-major fp32 unless stated; leading dimensions are in elements;
+ *     row starts must be 16-byte aligned (base pointer 16-byte aligned, ld a multiple of 4);
+ *   - calls are stream-ordered on `stream` (a hipStream_t passed as void*) and do not block the
+ *     host; plan creation/destruction are the only calls that allocate or synchronise;
+ *   - there is no CPU fallback: without a HIP device every compute entry point fails.
+ */
+#ifndef HYPMI_H
+#define HYPMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HYPMI_OK 0
+#define HYPMI_EINVAL (-1)  /* bad argument (shape, alignment, null pointer) */
+#define HYPMI_EHIP (-2)    /* a HIP runtime call failed                     */
+#define HYPMI_ENOMEM (-3)  /* device allocation failed                      */
+
+#define HYPMI_MAX_SEG 4
+
+/* Which side of a trial a packed vector is for: enrol-side rows carry [g, q, 1], test-side rows
+ * carry [g, 1, q + c], so that a plain dot product of the two is the log-likelihood ratio. */
+#define HYPMI_SIDE_ENROL 0
+#define HYPMI_SIDE_TEST 1
+
+typedef struct hypmi_plan hypmi_plan;
+
+/* One pre-processing segment: y = (x A + b), then optionally y <- sqrt(d_out) y / (|y| + 1e-10).
+ * A is [d_in x d_out] row-major fp64 on the HOST (NULL = identity, d_out must equal d_in),
+ * b is [d_out] fp64 on the host (NULL = 0). */
+typedef struct {
+    const double* A;
+    const double* b;
+    int32_t d_out;
+    int32_t lnorm;
+} hypmi_segment;
+
+/* Folded model: a chain of segments (hyperion/transforms/transform_list.py:41-44 with
+ * cent_whiten.py:25-33, lnorm.py:14-17, lda.py:31-34, pca.py:39-42 folded by the host) followed by
+ * the two K-dimensional projections of the PLDA model,
+ *   g = y At + bt   (the reference's gamma_tar, e.g. hyperion/pdfs/plda/splda.py:306-307)
+ *   h = y An + bn   (gamma_non, splda.py:300-301)
+ * and the additive constant c (splda.py:314-315: (2 logLnon - logLtar)/2).  At/An are
+ * [d_last x K] row-major fp64 host arrays, bt/bn [K] (NULL = 0).  The host computes them in fp64
+ * (Cholesky and triangular solves act on K x K matrices only). */
+typedef struct {
+    int32_t d_in;
+    int32_t n_seg;
+    hypmi_segment seg[HYPMI_MAX_SEG];
+    const double* At;
+    const double* bt;
+    const double* An;
+    const double* bn;
+    int32_t K;
+    double c;
+} hypmi_plan_desc;
+
+const char* hypmi_last_error(void);
+int hypmi_version(void);
+
+/* Create / destroy a device-resident plan on the current HIP device. */
+int hypmi_plan_create(const hypmi_plan_desc* desc, hypmi_plan** out);
+void hypmi_plan_destroy(hypmi_plan* plan);
+
+/* Width (in floats, a multiple of 8) of one packed row produced by hypmi_prologue for this plan:
+ * K + 2 rounded up to the width of the score kernel that will be used. */
+int hypmi_plan_kp(const hypmi_plan* plan);
+int hypmi_plan_k(const hypmi_plan* plan);
+int hypmi_plan_d_in(const hypmi_plan* plan);
+int hypmi_plan_d_out(const hypmi_plan* plan); /* dimension after the last segment */
+
+/* Packed row width for a K-dimensional projection that is packed outside a plan (book scoring). */
+int hypmi_packed_width(int K);
+
+/* Bytes of scratch hypmi_prologue / hypmi_transform need for n rows. */
+int64_t hypmi_prologue_workspace_bytes(const hypmi_plan* plan, int64_t n);
+
+/* Pre-processing chain + PLDA projection for n embeddings.
+ * Replaces TransformList.predict followed by the `np.dot(x - mu, WV)` / mult_icholL* / Q* lines of
+ * llr_1vs1 (hyperion/pdfs/plda/splda.py:297-310, frplda.py:278-292, plda.py:453-466).
+ * x: [n x d_in], ldx >= d_in rounded up to 4, pad columns zero.  G: [n x KP] packed rows. */
+int hypmi_prologue(const hypmi_plan* plan, const float* x, int64_t n, int64_t ldx, int side,
+                   float* G, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Only the segments (TransformList.predict, transform_list.py:41-44): y is [n x d_out]. */
+int hypmi_transform(const hypmi_plan* plan, const float* x, int64_t n, int64_t ldx, float* y,
+                    int64_t ldy, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Trial score matrix S[i,j] = <G1[i,:], G2[j,:]>  (= g1.g2 + q1 + q2 + c).
+ * Replaces `2*np.dot(gamma_tar_1, gamma_tar_2.T)` and the three broadcast passes of
+ * hyperion/pdfs/plda/splda.py:312-315 (frplda.py:294-302, plda.py:468-471).
+ * G1: [n1 x kp] enrol-side packed rows, G2: [n2 x kp] test-side packed rows, S: [n1 x n2], lds>=n2.
+ */
+int hypmi_score(const float* G1, int64_t n1, const float* G2, int64_t n2, int kp, float* S,
+                int64_t lds, void* stream);
+
+/* Generic y = x Wt^T + bias (one np.dot(x - mu, T) of the reference, with -mu T in bias).
+ * Wt is [d_out x ldw] (the transposed weight, rows padded with zeros to ldw). */
+int hypmi_affine(const float* x, int64_t n, int64_t ldx, int d_in, const float* Wt, int64_t ldw,
+                 const float* bias, int d_out, float* y, int64_t ldy, void* stream);
+
+/* In-place length normalisation of rows: y <- sqrt(d) y / (|y| + 1e-10)  (lnorm.py:16-17). */
+int hypmi_lnorm_rows(float* y, int64_t n, int64_t ldy, int d, void* stream);
+
+/* ---- multi-session enrolment (hyperion/pdfs/plda/plda_base.py:249-351) ---------------------- */
+
+/* Class pooling: out[g,:] = sum (mean != 0: average) of x[order[r],:], r in [offsets[g], offsets[g+1]).
+ * Replaces the per-class boolean-mask loop of compute_stats_hard (plda_base.py:259-266) and the
+ * F / N divisions of llr_NvsM_vavg / _savg (plda_base.py:307-308, 318-321).  `order` (int32) lists
+ * row numbers grouped by class, `offsets` (int64, n_groups + 1) delimits the groups; both are device
+ * arrays.  counts (optional) receives the class sizes as floats.  An empty class averages to NaN,
+ * as F / N does for N = 0. */
+int hypmi_pool_rows(const float* x, int64_t ldx, int d, const int32_t* order, const int64_t* offsets,
+                    int64_t n_groups, int mean, float* out, int64_t ldo, float* counts, void* stream);
+
+/* x[i,:] /= denom[i] in place: class sums to class means, F / N (plda_base.py:307-308). */
+int hypmi_div_rows(float* x, int64_t ldx, int64_t n, int d, const float* denom, void* stream);
+
+/* By-the-book packing of one (own count, total count) group (splda.py:334-375, frplda.py:320-362):
+ * from eigen-basis statistics s[n x K], g_k = (s_k + shift_t[k]) scale_t[k],
+ * h_k = (s_k + shift_n[k]) scale_n[k], q = (|g|^2 - |h|^2)/2, packed as in hypmi_prologue.
+ * rows (optional int32[n]) selects which rows of s are packed. */
+int hypmi_book_pack(const float* s, int64_t lds, int K, const int32_t* rows, int64_t n,
+                    const float* shift_t, const float* scale_t, const float* shift_n,
+                    const float* scale_n, int side, double c, float* G, int kp, void* stream);
+
+/* out[ri[a], ci[b]] = blk[a, b]: the `scores[np.ix_(i, j)] = scores_ij` of splda.py:376. */
+int hypmi_scatter_block(const float* blk, int64_t ldb, const int32_t* ri, int64_t nr, const int32_t* ci,
+                        int64_t nc, float* out, int64_t ldo, void* stream);
+
+/* ---- score normalisation (hyperion/score_norm) ---------------------------------------------- */
+
+/* Per-row top-k over the cohort: for every row of A[n_rows x nc] the cohort indices ranked
+ * discard .. discard+k-1 by descending score, written list-minor: idx_t[j * ldi + row], j < k, in
+ * ascending index order.  Replaces np.argsort + flip + slice (adapt_s_norm.py:42-44, 65-67); ties at
+ * a boundary are resolved towards the lower cohort index (numpy leaves that order unspecified).
+ * Cohorts up to ~40k entries are selected inside LDS; larger ones need the workspace. */
+int64_t hypmi_topk_workspace_bytes(int64_t n_rows, int nc);
+int hypmi_topk_rows(const float* A, int64_t n_rows, int nc, int64_t lda, int k, int discard,
+                    int32_t* idx_t, int64_t ldi, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Cohort statistics over selected members (adapt_s_norm.py:46-63 and 69-86): for every row r of
+ * X[n_rows x nc] and list q: mean[r,q] and istd[r,q] = 1 / max(std, std_floor) of X[r, idx_t[:, q]]
+ * (population std).  With mask (uint8 [n_rows x nc], 0 = masked, X already zeroed there) the moments
+ * are divided by the unmasked fraction as adapt_s_norm.py:54-60 does. */
+int hypmi_gather_stats(const float* X, int64_t n_rows, int nc, int64_t ldx, const unsigned char* mask,
+                       int64_t ldm, const int32_t* idx_t, int64_t ldi, int k, int64_t n_lists,
+                       float std_floor, float* mean, float* istd, int64_t ldo, void* stream);
+
+/* out[e,t] = ((S - mz[e,t]) iz[e,t] + (S - mt[t,e]) it[t,e]) / sqrt(2)  (adapt_s_norm.py:63,86,88). */
+int hypmi_asnorm_apply(const float* S, int64_t lds, int64_t ne, int64_t nt, const float* mz,
+                       const float* iz, int64_t ldz, const float* mt, const float* it, int64_t ldt,
+                       float* out, int64_t ldo, void* stream);
+
+/* X[i,j] = 0 where mask[i,j] == 0: `scores[mask == False] = 0` (adapt_s_norm.py:37-40,
+ * t_norm.py:21, z_norm.py:22), applied to the library's device copy, never to caller arrays. */
+int hypmi_mask_zero(float* X, int64_t rows, int64_t cols, int64_t ldx, const unsigned char* mask,
+                    int64_t ldm, void* stream);
+
+/* out[c, r] = in[r, c] (cohort-major score matrices to rows-over-cohort). */
+int hypmi_transpose(const float* in, int64_t rows, int64_t cols, int64_t ldi, float* out, int64_t ldo,
+                    void* stream);
+
+/* Whole-row mean and 1 / max(std, floor) (z_norm.py:18-29, t_norm.py:17-28). */
+int hypmi_row_meanstd(const float* X, int64_t n_rows, int nc, int64_t ldx, const unsigned char* mask,
+                      int64_t ldm, float std_floor, float* mean, float* istd, void* stream);
+
+/* out[e,t] = (S - mz[e]) iz[e]  and/or  (S - mt[t]) it[t]; both: sum / sqrt(2)
+ * (z_norm.py:31, t_norm.py:30, s_norm.py:31-34).  Pass NULL pairs to disable a part. */
+int hypmi_norm_apply(const float* S, int64_t lds, int64_t ne, int64_t nt, const float* mz,
+                     const float* iz, const float* mt, const float* it, float* out, int64_t ldo,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYPMI_H */

@@ -1,0 +1,292 @@
+"""Generate tests/golden/*.npz from the imported reference (run in the build container only).
+
+    python3 -B oracle/gen_golden.py
+
+TEST INFRASTRUCTURE.  Each fixture holds seeded inputs and the float64 outputs of the reference
+classes on them; the script also asserts that oracle/plda_ref.py reproduces every output to
+1e-10 (relative to the output scale), which is what pins the restatement.  The fixtures are
+data only: no reference source text is stored.
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+import numpy as np  # noqa: E402
+
+import load_ref  # noqa: E402
+import plda_ref as O  # noqa: E402
+import synth  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+R = load_ref.load()
+
+
+def close(a, b, tol=1e-10):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    scale = max(1.0, float(np.nanmax(np.abs(b)))) if b.size else 1.0
+    err = float(np.nanmax(np.abs(a - b))) if b.size else 0.0
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    assert err <= tol * scale, (err, scale)
+    return err
+
+
+def ref_model(m):
+    if m["type"] == "splda":
+        return R.SPLDA(mu=m["mu"].copy(), V=m["V"].copy(), W=m["W"].copy())
+    if m["type"] == "frplda":
+        return R.FRPLDA(mu=m["mu"].copy(), B=m["B"].copy(), W=m["W"].copy())
+    r = R.PLDA(mu=m["mu"].copy(), V=m["V"].copy(), U=m["U"].copy(), D=m["D"].copy())
+    assert r.is_init
+    r._WV = r._VW  # instance attribute so that the broken llr_NvsM_book (plda.py:481) can run
+    return r
+
+
+def small_models(d, K, seed):
+    rng = np.random.RandomState(seed)
+    V = rng.randn(K, d)
+    A = rng.randn(d, d)
+    W = A @ A.T / d + np.eye(d)
+    A2 = rng.randn(d, d)
+    B = A2 @ A2.T / d + 0.5 * np.eye(d)
+    return {
+        "splda": {"type": "splda", "mu": rng.randn(d), "V": V, "W": W},
+        "frplda": {"type": "frplda", "mu": rng.randn(d), "B": B, "W": 2 * W},
+        "plda": {"type": "plda", "mu": rng.randn(d), "V": V, "U": rng.randn(3, d),
+                 "D": np.abs(rng.randn(d)) + 1},
+    }
+
+
+def flat(prefix, m):
+    return {prefix + k: v for k, v in m.items() if k != "type"}
+
+
+def gen_selfcheck():
+    """Known answers printed by the survey session (loader self-check)."""
+    rng = np.random.RandomState(0)
+    d, yd = 16, 4
+    V = rng.randn(yd, d)
+    A = rng.randn(d, d)
+    W = A @ A.T / d + np.eye(d)
+    m = R.SPLDA(mu=rng.randn(d), V=V, W=W)
+    x = m.sample(5, 2, seed=1)
+    s = m.llr_1vs1(x[::2], x[1::2])
+    assert np.allclose(s[0, :3], [2.97965075, -7.73765166, -77.20524113], atol=1e-7)
+    fr = R.FRPLDA(mu=rng.randn(d), B=W, W=2 * W)
+    s2 = fr.llr_1vs1(x[::2], x[1::2])
+    assert np.allclose(s2[0, :2], [28.60123297, 1.69248982], atol=1e-7)
+    pl = R.PLDA(mu=rng.randn(d), V=V, U=rng.randn(3, d), D=np.abs(rng.randn(d)) + 1)
+    s3 = pl.llr_1vs1(x[::2], x[1::2])
+    assert np.allclose(s3[0, :2], [2.50270301, -8.85197729], atol=1e-7)
+    sc, ct, ec = rng.randn(6, 7), rng.randn(30, 7), rng.randn(6, 30)
+    s4 = R.AdaptSNorm(nbest=10).predict(sc, ct, ec)
+    assert np.allclose(s4[0, :3], [1.04342288, 0.54618728, -1.02196569], atol=1e-7)
+    print("selfcheck ok")
+
+
+def gen_1vs1():
+    out = {}
+    for d, K, n1, n2, tag in [(24, 6, 9, 11, "a"), (40, 12, 33, 70, "b")]:
+        models = small_models(d, K, seed=100 + d)
+        rng = np.random.RandomState(5 + d)
+        x1 = rng.randn(n1, d)
+        x2 = rng.randn(n2, d) * 1.5 + 0.1
+        out["x1_" + tag], out["x2_" + tag] = x1, x2
+        for name, m in models.items():
+            s = ref_model(m).llr_1vs1(x1, x2)
+            close(O.llr_1vs1(m, x1, x2), s)
+            out.update(flat("%s_%s_" % (name, tag), m))
+            out["%s_%s_scores" % (name, tag)] = s
+    np.savez_compressed(os.path.join(OUT, "llr_1vs1.npz"), **out)
+    print("llr_1vs1 ok")
+
+
+def gen_transforms():
+    rng = np.random.RandomState(11)
+    d, d2, d3, n = 20, 20, 7, 15
+    x = rng.randn(n, d) * 2 + 0.3
+    mu1, T1 = rng.randn(d), rng.randn(d, d2)
+    mu2, T2 = rng.randn(d2), rng.randn(d2, d3)
+    mu3, T3 = rng.randn(d), rng.randn(d, d3)
+    out = dict(x=x, mu1=mu1, T1=T1, mu2=mu2, T2=T2, mu3=mu3, T3=T3)
+    out["cw"] = R.CentWhiten(mu=mu1, T=T1).predict(x)
+    close(O.cent_whiten_predict(x, mu1, T1), out["cw"])
+    out["cw_noT"] = R.CentWhiten(mu=mu1, T=None).predict(x)
+    out["cw_nomu"] = R.CentWhiten(mu=None, T=T1).predict(x)
+    out["lnorm"] = R.LNorm(mu=mu1, T=T1).predict(x)
+    close(O.lnorm_predict(x, mu1, T1), out["lnorm"])
+    out["lnorm_plain"] = R.LNorm().predict(x)
+    close(O.lnorm_predict(x), out["lnorm_plain"])
+    out["lda"] = R.LDA(mu=mu3, T=T3).predict(x)
+    close(O.lda_predict(x, mu3, T3), out["lda"])
+    out["pca"] = R.PCA(mu=mu3, T=T3).predict(x)
+    out["pca_nomu"] = R.PCA(mu=None, T=T3).predict(x)
+    # recipe order LDA -> LNorm (egs/voxceleb/v1/steps_be/train-be-v1.py:92)
+    tl = R.TransformList([R.LDA(mu=mu3, T=T3, name="lda"), R.LNorm(name="ln")])
+    out["chain_lda_lnorm"] = tl.predict(x)
+    close(O.chain_predict(x, [("lda", mu3, T3), ("lnorm", None, None)]), out["chain_lda_lnorm"])
+    # benchmark order CentWhiten -> LNorm -> LDA
+    tl = R.TransformList([R.CentWhiten(mu=mu1, T=T1, name="cw"), R.LNorm(name="ln"),
+                          R.LDA(mu=mu2, T=T2, name="lda")])
+    out["chain_cw_lnorm_lda"] = tl.predict(x)
+    close(O.chain_predict(x, [("cw", mu1, T1), ("lnorm", None, None), ("lda", mu2, T2)]),
+          out["chain_cw_lnorm_lda"])
+    # two length norms: PCA -> LNorm(mu,T) -> LDA -> LNorm
+    tl = R.TransformList([R.PCA(mu=mu1, T=T1, name="pca"), R.LNorm(mu=mu2, T=None, name="ln1"),
+                          R.LDA(mu=mu2, T=T2, name="lda"), R.LNorm(name="ln2")])
+    out["chain_two_norms"] = tl.predict(x)
+    close(O.chain_predict(x, [("pca", mu1, T1), ("lnorm", mu2, None), ("lda", mu2, T2),
+                              ("lnorm", None, None)]), out["chain_two_norms"])
+    # zero vector through LNorm (the +1e-10 guard)
+    xz = x.copy()
+    xz[3] = 0
+    out["x_zero_row"] = xz
+    out["lnorm_zero_row"] = R.LNorm().predict(xz)
+    close(O.lnorm_predict(xz), out["lnorm_zero_row"])
+    np.savez_compressed(os.path.join(OUT, "transforms.npz"), **out)
+    print("transforms ok")
+
+
+def gen_nvsm():
+    d, K = 40, 12
+    models = small_models(d, K, seed=77)
+    rng = np.random.RandomState(8)
+    # enrol: mixed counts {1,2,3}, ids not sorted; test: counts {1,2}
+    ids1 = np.array([0, 0, 0, 1, 2, 2, 3, 3, 3, 4, 5, 5, 6, 6, 6, 7])
+    perm = rng.permutation(len(ids1))
+    ids1 = ids1[perm]
+    ids2 = np.array([0, 1, 1, 2, 3, 3, 4, 5, 6, 6, 7, 8, 9, 9])
+    x1 = rng.randn(len(ids1), d)
+    x2 = rng.randn(len(ids2), d) + 0.2
+    out = dict(x1=x1, x2=x2, ids1=ids1, ids2=ids2)
+    for name, m in models.items():
+        out.update(flat(name + "_", m))
+        for method in ["book", "vavg", "vavg-lnorm", "savg"]:
+            key = method.replace("-", "_")
+            s = ref_model(m).llr_NvsM(x1.copy(), x2.copy(), ids1=ids1, ids2=ids2, method=method)
+            close(O.llr_NvsM(m, x1, x2, ids1, ids2, method), s)
+            out["%s_NvsM_%s" % (name, key)] = s
+            s = ref_model(m).llr_Nvs1(x1.copy(), x2.copy(), ids1=ids1, method=method)
+            close(O.llr_Nvs1(m, x1, x2, ids1, method), s)
+            out["%s_Nvs1_%s" % (name, key)] = s
+        # stats passed directly (ids=None): D = (N, F, S)
+        N1, F1, _ = O.compute_stats_hard(x1, ids1)
+        N2, F2, _ = O.compute_stats_hard(x2, ids2)
+        s = ref_model(m).llr_NvsM((N1, F1.copy(), None), (N2, F2.copy(), None), method="book")
+        close(s, out["%s_NvsM_book" % name])
+    # compute_stats_hard itself, incl. an id that never occurs (class 2 missing)
+    idsg = np.array([0, 1, 1, 3, 3, 3])
+    xg = rng.randn(6, 5)
+    N, F, S = R.SPLDA.compute_stats_hard(xg, idsg)
+    No, Fo, _ = O.compute_stats_hard(xg, idsg)
+    close(No, N)
+    close(Fo, F)
+    out.update(stats_x=xg, stats_ids=idsg, stats_N=N, stats_F=F)
+    np.savez_compressed(os.path.join(OUT, "llr_NvsM.npz"), **out)
+    print("NvsM ok")
+
+
+def gen_score_norm():
+    rng = np.random.RandomState(21)
+    ne, nt, nc = 13, 17, 64
+    sc = rng.randn(ne, nt) * 5 - 3
+    ct = rng.randn(nc, nt) * 4 - 6
+    ec = rng.randn(ne, nc) * 4 - 6
+    out = dict(scores=sc, coh_test=ct, enr_coh=ec)
+    for nbest, disc, tag in [(10, 0, "n10"), (20, 3, "n20d3"), (100, 0, "clamp"), (100, 60, "clampd")]:
+        s = R.AdaptSNorm(nbest=nbest, nbest_discard=disc).predict(sc.copy(), ct.copy(), ec.copy())
+        close(O.adapt_s_norm(sc, ct, ec, nbest, disc), s)
+        out["asnorm_" + tag] = s
+    mct = rng.rand(nc, nt) > 0.2
+    mec = rng.rand(ne, nc) > 0.2
+    out.update(mask_coh_test=mct, mask_enr_coh=mec)
+    s = R.AdaptSNorm(nbest=10).predict(sc.copy(), ct.copy(), ec.copy(), mct, mec)
+    close(O.adapt_s_norm(sc, ct, ec, 10, 0, mct, mec), s)
+    out["asnorm_masked"] = s
+    s = R.SNorm().predict(sc.copy(), ct.copy(), ec.copy())
+    close(O.s_norm(sc, ct, ec), s)
+    out["snorm"] = s
+    s = R.SNorm().predict(sc.copy(), ct.copy(), ec.copy(), mct, mec)
+    close(O.s_norm(sc, ct, ec, mct, mec), s)
+    out["snorm_masked"] = s
+    out["tnorm"] = R.TNorm().predict(sc.copy(), ct.copy())
+    close(O.t_norm(sc, ct), out["tnorm"])
+    out["znorm"] = R.ZNorm().predict(sc.copy(), ec.copy())
+    close(O.z_norm(sc, ec), out["znorm"])
+    # constant cohort -> std floor
+    ec0 = np.full_like(ec, 1.5)
+    out["enr_coh_const"] = ec0
+    out["znorm_floor"] = R.ZNorm().predict(sc.copy(), ec0.copy())
+    close(O.z_norm(sc, ec0), out["znorm_floor"])
+    out["asnorm_floor"] = R.AdaptSNorm(nbest=10).predict(sc.copy(), ct.copy(), ec0.copy())
+    close(O.adapt_s_norm(sc, ct, ec0, 10, 0), out["asnorm_floor"])
+    np.savez_compressed(os.path.join(OUT, "score_norm.npz"), **out)
+    print("score_norm ok")
+
+
+def gen_metrics():
+    out = {}
+    # the reference's own test inputs (tests/hyperion/metrics/test_eer.py:14-29,
+    # test_dcf.py:14-44): tar = linspace(-2,10,1000)+3, non = linspace(-10,2,1000)+3
+    tar = np.linspace(-2, 10, 1000) + 3
+    non = np.linspace(-10, 2, 1000) + 3
+    eer = R.compute_eer(tar, non)
+    assert 0.166 < eer < 0.167
+    close(O.compute_eer(tar, non), eer)
+    dcf = R.compute_min_dcf(tar, non, 0.5)[0]
+    assert 0.332 < dcf < 0.334
+    close(O.compute_min_dcf(tar, non, 0.5)[0], dcf)
+    out.update(lin_eer=eer, lin_min_dcf=dcf)
+    rng = np.random.RandomState(4)
+    tar = rng.randn(400) * 4 + 8
+    non = rng.randn(3000) * 8 - 14
+    out.update(tar=tar, non=non, eer=R.compute_eer(tar, non),
+               min_dcf_005=R.compute_min_dcf(tar, non, 0.05)[0],
+               min_dcf_001=R.compute_min_dcf(tar, non, 0.01)[0])
+    close(O.compute_eer(tar, non), out["eer"])
+    close(O.compute_min_dcf(tar, non, 0.05)[0], out["min_dcf_005"])
+    close(O.compute_min_dcf(tar, non, 0.01)[0], out["min_dcf_001"])
+    # math helpers (tests/hyperion/utils/test_math.py pins them against scipy inv/det)
+    A = rng.randn(9, 9)
+    A = A @ A.T + np.eye(9)
+    X = rng.randn(4, 9)
+    fh, Rch, logdet, invA = R.math.invert_pdmat(A, right_inv=True, return_logdet=True, return_inv=True)
+    out.update(pd_A=A, pd_X=X, pd_logdet=logdet, pd_inv=invA, pd_XiA=fh(X))
+    close(O.logdet_pdmat(A), logdet)
+    close(O.inv_pdmat(A), invA)
+    fh, logdetR = R.math.invert_trimat(Rch, right_inv=True, return_logdet=True)[:2]
+    out.update(tri_R=Rch, tri_XiR=fh(X), tri_logdet=logdetR)
+    close(O.right_solve_upper(Rch, X), out["tri_XiR"])
+    np.savez_compressed(os.path.join(OUT, "metrics_math.npz"), **out)
+    print("metrics ok")
+
+
+def gen_medium():
+    """A mid-size SPLDA case on the calibrated synthetic model (scores cross zero) plus the
+    benchmark chain, for the GPU parity tests: reference scores for 96 x 160 trials at d=64."""
+    m = synth.make_splda(64, 20)
+    x = synth.length_norm(synth.sample_splda(m, 32, 8, seed=7))
+    x1, x2 = x[::2][:96], x[1::2][:160]
+    s = ref_model(m).llr_1vs1(x1, x2)
+    close(O.llr_1vs1(m, x1, x2), s)
+    out = dict(x1=x1.astype(np.float32), x2=x2.astype(np.float32), scores=s)
+    out.update(flat("m_", m))
+    # x stored as float32 to keep the file small; scores are for the float32-rounded inputs
+    s = ref_model(m).llr_1vs1(out["x1"].astype(float), out["x2"].astype(float))
+    out["scores"] = s
+    np.savez_compressed(os.path.join(OUT, "splda_medium.npz"), **out)
+    print("medium ok")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    gen_selfcheck()
+    gen_1vs1()
+    gen_transforms()
+    gen_nvsm()
+    gen_score_norm()
+    gen_metrics()
+    gen_medium()

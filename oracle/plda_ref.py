@@ -1,0 +1,457 @@
+"""CPU oracle: float64 numpy restatement of the reference's PLDA back-end scoring path.
+
+TEST INFRASTRUCTURE ONLY.  This module is the checker for the HIP path: it may be imported by
+tests/, by __graft_entry__.smoke() and by bench.py's cpu_baseline leg, and by nothing else.  The
+product package (hyperion_amd/) never imports it and has no CPU fallback.
+
+Every function follows the reference's operation order (same numpy/scipy calls in the same
+sequence) so that it can double as the "port" CPU baseline; the reference location it restates is
+cited in each docstring (paths relative to the reference tree).  Parity of this restatement is
+pinned by tests/golden/*.npz, produced by oracle/gen_golden.py from the imported reference.
+
+All arithmetic is float64, embeddings are rows.
+"""
+import numpy as np
+import scipy.linalg as sla
+
+F64 = np.float64
+
+
+# ----------------------------------------------------------------------------- utils/math.py
+def right_solve_upper(R, X):
+    """X @ inv(R) for upper-triangular R (hyperion/utils/math.py:81-82, right_inv branch)."""
+    return sla.solve_triangular(R.T, X.T, lower=True).T
+
+
+def chol_upper(A):
+    """Upper Cholesky factor R with R.T @ R = A (scipy default used at utils/math.py:17,38)."""
+    return sla.cholesky(np.array(A, dtype=F64), lower=False)
+
+
+def logdet_pdmat(A):
+    """hyperion/utils/math.py:14-18."""
+    return 2.0 * np.sum(np.log(np.diag(chol_upper(A))))
+
+
+def inv_pdmat(A):
+    """A^{-1} through cho_solve (hyperion/utils/math.py:38-57 with return_inv=True)."""
+    R = chol_upper(A)
+    return sla.cho_solve((R, False), np.eye(A.shape[0]))
+
+
+# ----------------------------------------------------------------------------- transforms
+def cent_whiten_predict(x, mu=None, T=None):
+    """hyperion/transforms/cent_whiten.py:25-33.  The 1-D T branch of the reference raises
+    NameError (bare `T`); the evident intent, x * T, is what is restated here."""
+    if mu is not None:
+        x = x - mu
+    if T is not None:
+        x = x * T if T.ndim == 1 else np.dot(x, T)
+    return x
+
+
+def lnorm_predict(x, mu=None, T=None):
+    """hyperion/transforms/lnorm.py:14-17."""
+    x = cent_whiten_predict(x, mu, T)
+    mx = np.sqrt(np.sum(x ** 2, axis=1, keepdims=True)) + 1e-10
+    return np.sqrt(x.shape[1]) * x / mx
+
+
+def lda_predict(x, mu, T):
+    """hyperion/transforms/lda.py:31-34 and pca.py:39-42 (identical arithmetic)."""
+    if mu is not None:
+        x = x - mu
+    return np.dot(x, T)
+
+
+def chain_predict(x, chain):
+    """hyperion/transforms/transform_list.py:41-44.  `chain` is a list of
+    (kind, mu, T) with kind in {"cw", "lnorm", "lda", "pca"}."""
+    for kind, mu, T in chain:
+        if kind == "cw":
+            x = cent_whiten_predict(x, mu, T)
+        elif kind == "lnorm":
+            x = lnorm_predict(x, mu, T)
+        elif kind in ("lda", "pca"):
+            x = lda_predict(x, mu, T)
+        else:
+            raise ValueError(kind)
+    return x
+
+
+# ----------------------------------------------------------------------------- PLDA 1-vs-1
+def _combine(gt1, gt2, gn1, gn2, const):
+    """Common tail of every llr_1vs1 (e.g. hyperion/pdfs/plda/splda.py:303-316)."""
+    Qnon_1 = np.sum(gn1 * gn1, axis=1)[:, None]
+    Qnon_2 = np.sum(gn2 * gn2, axis=1)
+    Qtar_1 = np.sum(gt1 * gt1, axis=1)[:, None]
+    Qtar_2 = np.sum(gt2 * gt2, axis=1)
+    scores = 2 * np.dot(gt1, gt2.T)
+    scores += Qtar_1 - Qnon_1 + Qtar_2 - Qnon_2
+    scores += const
+    scores *= 0.5
+    return scores
+
+
+def _llr_from_WV(x1, x2, mu, WV, VV):
+    """Shared body of SPLDA.llr_1vs1 (splda.py:279-316) and PLDA.llr_1vs1 (plda.py:435-472)."""
+    I = np.eye(VV.shape[0], dtype=F64)
+    Rnon = chol_upper(I + VV)
+    logLnon = 2 * np.sum(np.log(np.diag(Rnon)))
+    Rtar = chol_upper(I + 2 * VV)
+    logLtar = 2 * np.sum(np.log(np.diag(Rtar)))
+    VWF1 = np.dot(x1 - mu, WV)
+    VWF2 = np.dot(x2 - mu, WV)
+    gn1 = right_solve_upper(Rnon, VWF1)
+    gn2 = right_solve_upper(Rnon, VWF2)
+    gt1 = right_solve_upper(Rtar, VWF1)
+    gt2 = right_solve_upper(Rtar, VWF2)
+    return _combine(gt1, gt2, gn1, gn2, 2 * logLnon - logLtar)
+
+
+def splda_llr_1vs1(x1, x2, mu, V, W):
+    """hyperion/pdfs/plda/splda.py:275-316.  V is [y_dim, d]; W is the d x d within-class
+    precision."""
+    WV = np.dot(W, V.T)
+    VV = np.dot(V, WV)
+    return _llr_from_WV(x1, x2, mu, WV, VV)
+
+
+def plda_aux(V, U, D):
+    """hyperion/pdfs/plda/plda.py:77-89: returns (_VW [d, y_dim], _VWV [y_dim, y_dim])."""
+    DV = V * D
+    DU = U * D
+    J = np.dot(V, DU.T)
+    Lz = np.eye(U.shape[0], dtype=F64) + np.dot(DU, U.T)
+    Rz = chol_upper(Lz)
+    DUiLz = sla.cho_solve((Rz, False), DU).T  # == mult_iLz(DU.T) with right_inv=True
+    VW = DV.T - np.dot(DUiLz, J.T)
+    VWV = np.dot(V, VW)
+    return VW, VWV
+
+
+def plda_llr_1vs1(x1, x2, mu, V, U, D):
+    """hyperion/pdfs/plda/plda.py:430-472."""
+    VW, VWV = plda_aux(V, U, D)
+    return _llr_from_WV(x1, x2, mu, VW, VWV)
+
+
+def frplda_llr_1vs1(x1, x2, mu, B, W):
+    """hyperion/pdfs/plda/frplda.py:258-303."""
+    Rnon = chol_upper(B + W)
+    logLnon = 2 * np.sum(np.log(np.diag(Rnon)))
+    Rtar = chol_upper(B + 2 * W)
+    logLtar = 2 * np.sum(np.log(np.diag(Rtar)))
+    WF1 = np.dot(x1, W)
+    WF2 = np.dot(x2, W)
+    Bmu = np.dot(mu, B)
+    gn1 = right_solve_upper(Rnon, WF1 + Bmu)
+    gn2 = right_solve_upper(Rnon, WF2 + Bmu)
+    gt1 = right_solve_upper(Rtar, WF1 + 0.5 * Bmu)
+    gt2 = right_solve_upper(Rtar, WF2 + 0.5 * Bmu)
+    const = 2 * logLnon - logLtar - logdet_pdmat(B) + np.inner(np.dot(mu, B), mu)
+    return _combine(gt1, gt2, gn1, gn2, const)
+
+
+def llr_1vs1(model, x1, x2):
+    """Dispatch on a model dict {"type": "splda"|"plda"|"frplda", params...}."""
+    t = model["type"]
+    if t == "splda":
+        return splda_llr_1vs1(x1, x2, model["mu"], model["V"], model["W"])
+    if t == "plda":
+        return plda_llr_1vs1(x1, x2, model["mu"], model["V"], model["U"], model["D"])
+    if t == "frplda":
+        return frplda_llr_1vs1(x1, x2, model["mu"], model["B"], model["W"])
+    raise ValueError(t)
+
+
+# ----------------------------------------------------------------------------- N-vs-M
+def compute_stats_hard(x, class_ids):
+    """hyperion/pdfs/plda/plda_base.py:249-274 without sample weights.  Classes are
+    0..max(id); an id that never occurs gives N = 0 and F = 0 (later 0/0 = NaN, as in the
+    reference).  The second-order statistic is returned as None: no scoring path reads it."""
+    num_classes = int(np.max(class_ids)) + 1
+    N = np.zeros((num_classes,), dtype=F64)
+    F = np.zeros((num_classes, x.shape[1]), dtype=F64)
+    for i in range(num_classes):
+        idx = class_ids == i
+        N[i] = np.sum(idx)
+        F[i] = np.sum(x[idx], axis=0)
+    return N, F, None
+
+
+def _book_pair(F1, F2, n1, n2, proj_non, proj_tar, logL):
+    """One (N1_i, N2_j) block of llr_NvsM_book (splda.py:332-376).  proj_non(n) / proj_tar(n)
+    map first-order stats to gamma_non / gamma_tar for count n."""
+    gn1 = proj_non(n1)(F1)
+    gn2 = proj_non(n2)(F2)
+    gt1 = proj_tar(n1 + n2)(F1)
+    gt2 = proj_tar(n1 + n2)(F2)
+    Qnon_1 = np.sum(gn1 * gn1, axis=1)[:, None]
+    Qnon_2 = np.sum(gn2 * gn2, axis=1)
+    Qtar_1 = np.sum(gt1 * gt1, axis=1)[:, None]
+    Qtar_2 = np.sum(gt2 * gt2, axis=1)
+    s = 2 * np.dot(gt1, gt2.T)
+    s += Qtar_1 - Qnon_1 + Qtar_2 - Qnon_2
+    s += logL(n1) + logL(n2) - logL(n1 + n2)
+    return s
+
+
+def llr_NvsM_book(model, D1, D2):
+    """SPLDA splda.py:318-379, FRPLDA frplda.py:305-366, PLDA plda.py:474-539.  The PLDA
+    version of the reference raises AttributeError (`self._WV` is never set); the evident
+    intent, `_VW` from compute_aux, is restated.  Unlike the reference this does not subtract
+    N*mu from the caller's F in place."""
+    N1, F1 = np.asarray(D1[0], F64), np.array(D1[1], dtype=F64)
+    N2, F2 = np.asarray(D2[0], F64), np.array(D2[1], dtype=F64)
+    t = model["type"]
+    mu = model["mu"]
+    if t in ("splda", "plda"):
+        if t == "splda":
+            WV = np.dot(model["W"], model["V"].T)
+            VV = np.dot(model["V"], WV)
+        else:
+            WV, VV = plda_aux(model["V"], model["U"], model["D"])
+        I = np.eye(VV.shape[0], dtype=F64)
+        F1 = F1 - N1[:, None] * mu
+        F2 = F2 - N2[:, None] * mu
+
+        def proj(n):
+            R = chol_upper(I + n * VV)
+            return lambda F: right_solve_upper(R, np.dot(F, WV))
+
+        def logL(n):
+            return 2 * np.sum(np.log(np.diag(chol_upper(I + n * VV))))
+
+        proj_non = proj_tar = proj
+        tail = 0.0
+    elif t == "frplda":
+        B, W = model["B"], model["W"]
+        Bmu = np.dot(mu, B)
+
+        def proj_non(n):
+            R = chol_upper(B + n * W)
+            return lambda F: right_solve_upper(R, np.dot(F, W) + Bmu)
+
+        def proj_tar(n):
+            R = chol_upper(B + n * W)
+            return lambda F: right_solve_upper(R, np.dot(F, W) + 0.5 * Bmu)
+
+        def logL(n):
+            return 2 * np.sum(np.log(np.diag(chol_upper(B + n * W))))
+
+        tail = -logdet_pdmat(B) + np.inner(np.dot(mu, B), mu)
+    else:
+        raise ValueError(t)
+
+    scores = np.zeros((len(N1), len(N2)), dtype=F64)
+    for n1 in np.unique(N1):
+        for n2 in np.unique(N2):
+            i = np.where(N1 == n1)[0]
+            j = np.where(N2 == n2)[0]
+            scores[np.ix_(i, j)] = _book_pair(F1[i], F2[j], n1, n2, proj_non, proj_tar, logL)
+    scores += tail
+    scores *= 0.5
+    return scores
+
+
+def llr_NvsM(model, x1, x2, ids1=None, ids2=None, method="vavg-lnorm"):
+    """hyperion/pdfs/plda/plda_base.py:292-322.  ids=None means x already is (N, F, S)."""
+    if method == "savg":
+        s11 = llr_1vs1(model, x1, x2)
+        N, F, _ = compute_stats_hard(s11, ids1)
+        sN1 = F / N[:, None]
+        N, F, _ = compute_stats_hard(sN1.T, ids2)
+        return F.T / N
+    D1 = x1 if ids1 is None else compute_stats_hard(x1, ids1)
+    D2 = x2 if ids2 is None else compute_stats_hard(x2, ids2)
+    if method == "book":
+        return llr_NvsM_book(model, D1, D2)
+    a1 = D1[1] / np.expand_dims(D1[0], axis=-1)
+    a2 = D2[1] / np.expand_dims(D2[0], axis=-1)
+    if method == "vavg-lnorm":
+        a1 = lnorm_predict(a1)
+        a2 = lnorm_predict(a2)
+    elif method != "vavg":
+        raise ValueError(method)
+    return llr_1vs1(model, a1, a2)
+
+
+def llr_Nvs1(model, x1, x2, ids1=None, method="vavg-lnorm"):
+    """hyperion/pdfs/plda/plda_base.py:324-351."""
+    if method == "savg":
+        s11 = llr_1vs1(model, x1, x2)
+        N, F, _ = compute_stats_hard(s11, ids1)
+        return F / N[:, None]
+    D1 = x1 if ids1 is None else compute_stats_hard(x1, ids1)
+    if method == "book":
+        D2 = compute_stats_hard(x2, np.arange(x2.shape[0]))
+        return llr_NvsM_book(model, D1, D2)
+    a1 = D1[1] / np.expand_dims(D1[0], axis=-1)
+    if method == "vavg-lnorm":
+        a1 = lnorm_predict(a1)
+        x2 = lnorm_predict(x2)
+    elif method != "vavg":
+        raise ValueError(method)
+    return llr_1vs1(model, a1, x2)
+
+
+# ----------------------------------------------------------------------------- score norm
+def adapt_s_norm(scores, scores_coh_test, scores_enr_coh, nbest=100, nbest_discard=0,
+                 mask_coh_test=None, mask_enr_coh=None):
+    """hyperion/score_norm/adapt_s_norm.py:21-88.  The reference zeroes masked cohort scores in
+    the caller's arrays; this restatement works on copies.  The std floor is the literal 1e-5 of
+    adapt_s_norm.py:62,85."""
+    assert scores_enr_coh.shape[1] == scores_coh_test.shape[0]
+    assert nbest_discard < scores_enr_coh.shape[1]
+    nbest = min(nbest, scores_enr_coh.shape[1] - nbest_discard)
+    if mask_coh_test is not None:
+        scores_coh_test = np.where(mask_coh_test, scores_coh_test, 0.0)
+    if mask_enr_coh is not None:
+        scores_enr_coh = np.where(mask_enr_coh, scores_enr_coh, 0.0)
+
+    best_idx = np.flipud(np.argsort(scores_coh_test, axis=0))[nbest_discard:nbest_discard + nbest]
+    z = np.zeros_like(scores)
+    for i in range(scores.shape[1]):
+        sel = best_idx[:, i]
+        mu_z = np.mean(scores_enr_coh[:, sel], axis=1, keepdims=True)
+        if mask_enr_coh is None:
+            s_z = np.std(scores_enr_coh[:, sel], axis=1, keepdims=True)
+        else:
+            norm = np.mean(mask_enr_coh[:, sel], axis=1, keepdims=True)
+            mu_z = mu_z / norm
+            s_z = np.sqrt(np.mean(scores_enr_coh[:, sel] ** 2, axis=1, keepdims=True) / norm
+                          - mu_z ** 2)
+        s_z = np.clip(s_z, a_min=1e-5, a_max=None)
+        z[:, i] = ((scores[:, i:i + 1] - mu_z) / s_z)[:, 0]
+
+    best_idx = np.fliplr(np.argsort(scores_enr_coh, axis=1))[:, nbest_discard:nbest_discard + nbest]
+    t = np.zeros_like(scores)
+    for i in range(scores.shape[0]):
+        sel = best_idx[i]
+        mu_t = np.mean(scores_coh_test[sel, :], axis=0, keepdims=True)
+        if mask_coh_test is None:
+            s_t = np.std(scores_coh_test[sel, :], axis=0, keepdims=True)
+        else:
+            norm = np.mean(mask_coh_test[sel, :], axis=0, keepdims=True)
+            mu_t = mu_t / norm
+            s_t = np.sqrt(np.mean(scores_coh_test[sel, :] ** 2, axis=0, keepdims=True) / norm
+                          - mu_t ** 2)
+        s_t = np.clip(s_t, a_min=1e-5, a_max=None)
+        t[i, :] = (scores[i:i + 1, :] - mu_t) / s_t
+    return (z + t) / np.sqrt(2)
+
+
+def z_norm(scores, scores_enr_coh, mask=None, std_floor=1e-5):
+    """hyperion/score_norm/z_norm.py:16-32 (on a copy of the cohort scores)."""
+    if mask is None:
+        mu = np.mean(scores_enr_coh, axis=1, keepdims=True)
+        s = np.std(scores_enr_coh, axis=1, keepdims=True)
+    else:
+        c = np.where(mask, scores_enr_coh, 0.0)
+        n = np.mean(mask, axis=1, keepdims=True)
+        mu = np.mean(c, axis=1, keepdims=True) / n
+        s = np.sqrt(np.mean(c ** 2, axis=1, keepdims=True) / n - mu ** 2)
+    s = np.where(s < std_floor, std_floor, s)
+    return (scores - mu) / s
+
+
+def t_norm(scores, scores_coh_test, mask=None, std_floor=1e-5):
+    """hyperion/score_norm/t_norm.py:15-31 (on a copy of the cohort scores)."""
+    if mask is None:
+        mu = np.mean(scores_coh_test, axis=0, keepdims=True)
+        s = np.std(scores_coh_test, axis=0, keepdims=True)
+    else:
+        c = np.where(mask, scores_coh_test, 0.0)
+        n = np.mean(mask, axis=0, keepdims=True)
+        mu = np.mean(c, axis=0, keepdims=True) / n
+        s = np.sqrt(np.mean(c ** 2, axis=0, keepdims=True) / n - mu ** 2)
+    s = np.where(s < std_floor, std_floor, s)
+    return (scores - mu) / s
+
+
+def s_norm(scores, scores_coh_test, scores_enr_coh, mask_coh_test=None, mask_enr_coh=None,
+           std_floor=1e-5):
+    """hyperion/score_norm/s_norm.py:22-34."""
+    z = z_norm(scores, scores_enr_coh, mask_enr_coh, std_floor)
+    t = t_norm(scores, scores_coh_test, mask_coh_test, std_floor)
+    return (z + t) / np.sqrt(2)
+
+
+# ----------------------------------------------------------------------------- metrics (gate)
+def pavx(y):
+    """Pool-adjacent-violators (hyperion/metrics/utils.py:30-94): returns (ghat, width, height)."""
+    n = len(y)
+    assert n > 0
+    start = np.zeros(n, dtype=int)
+    width = np.zeros(n, dtype=int)
+    level = np.zeros(n, dtype=F64)
+    ci = 0
+    start[0], width[0], level[0] = 0, 1, y[0]
+    for j in range(1, n):
+        ci += 1
+        start[ci], width[ci], level[ci] = j, 1, y[j]
+        while ci >= 1 and level[ci - 1] >= level[ci]:
+            nw = width[ci - 1] + width[ci]
+            level[ci - 1] = level[ci - 1] + (width[ci] / nw) * (level[ci] - level[ci - 1])
+            width[ci - 1] = nw
+            ci -= 1
+    ghat = np.repeat(level[:ci + 1], width[:ci + 1])
+    return ghat, width[:ci + 1].copy(), level[:ci + 1].copy()
+
+
+def compute_rocch(tar, non):
+    """ROC convex hull vertices (hyperion/metrics/roc.py:54-102)."""
+    Nt, Nn = len(tar), len(non)
+    N = Nt + Nn
+    scores = np.hstack((tar.ravel(), non.ravel()))
+    pideal = np.hstack((np.ones(Nt), np.zeros(Nn)))
+    order = np.argsort(scores, kind="mergesort")
+    pideal = pideal[order]
+    _, width, _ = pavx(pideal)
+    nbins = len(width)
+    p_miss = np.zeros(nbins + 1)
+    p_fa = np.zeros(nbins + 1)
+    csum = np.concatenate(([0.0], np.cumsum(pideal)))
+    left, fa, miss = 0, Nn, 0
+    for i in range(nbins):
+        p_miss[i] = miss / Nt
+        p_fa[i] = fa / Nn
+        left += width[i]
+        miss = csum[left]
+        fa = N - left - (csum[N] - csum[left])
+    p_miss[nbins] = miss / Nt
+    p_fa[nbins] = fa / Nn
+    return p_miss, p_fa
+
+
+def rocch2eer(p_miss, p_fa):
+    """hyperion/metrics/roc.py:105-140."""
+    eer = 0.0
+    for i in range(len(p_fa) - 1):
+        xx = p_fa[i:i + 2]
+        yy = p_miss[i:i + 2]
+        XY = np.vstack((xx, yy)).T
+        dd = np.dot(np.array([1, -1]), XY)
+        if np.min(np.abs(dd)) == 0:
+            eerseg = 0.0
+        else:
+            seg = sla.solve(XY, np.array([[1.0], [1.0]]))
+            eerseg = 1.0 / np.sum(seg)
+        eer = max(eer, eerseg)
+    return eer
+
+
+def compute_eer(tar, non):
+    """hyperion/metrics/eer.py:11-22."""
+    return rocch2eer(*compute_rocch(tar, non))
+
+
+def compute_min_dcf(tar, non, prior, normalize=True):
+    """hyperion/metrics/dcf.py:36-65 for a scalar prior: returns (min_dcf, p_miss, p_fa)."""
+    p_miss, p_fa = compute_rocch(tar, non)
+    dcf = prior * p_miss + (1 - prior) * p_fa
+    if normalize:
+        dcf = dcf / min(prior, 1 - prior)
+    i = int(np.argmin(dcf))
+    return dcf[i], p_miss[i], p_fa[i]

@@ -1,0 +1,136 @@
+"""The CPU oracle (oracle/plda_ref.py) against the fixtures produced from the reference itself
+(tests/golden/*.npz, made by oracle/gen_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+from conftest import model_from
+from oracle import plda_ref as O
+
+TOL = 1e-10
+
+
+def close(a, b, tol=TOL):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    assert a.shape == b.shape
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    scale = max(1.0, float(np.nanmax(np.abs(b)))) if b.size else 1.0
+    err = float(np.nanmax(np.abs(a - b))) if b.size else 0.0
+    assert err <= tol * scale, (err, scale)
+
+
+@pytest.mark.parametrize("kind", ["splda", "frplda", "plda"])
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_llr_1vs1(golden, kind, tag):
+    g = golden("llr_1vs1")
+    m = model_from(g, "%s_%s_" % (kind, tag), kind)
+    close(O.llr_1vs1(m, g["x1_" + tag], g["x2_" + tag]), g["%s_%s_scores" % (kind, tag)])
+
+
+def test_known_answers():
+    """Values printed by the reference in the survey session for seeded toy models."""
+    rng = np.random.RandomState(0)
+    d, yd = 16, 4
+    V = rng.randn(yd, d)
+    A = rng.randn(d, d)
+    W = A @ A.T / d + np.eye(d)
+    m = {"type": "splda", "mu": rng.randn(d), "V": V, "W": W}
+    # SPLDA.sample(5, 2, seed=1): noise first, then speaker factors
+    import scipy.linalg as sla
+    r1 = np.random.RandomState(1)
+    z = r1.normal(size=(10, d)) @ sla.cholesky(O.inv_pdmat(W), lower=False)
+    y = np.repeat(r1.normal(size=(5, yd)) @ V + m["mu"], 2, axis=0)
+    x = y + z
+    s = O.llr_1vs1(m, x[::2], x[1::2])
+    assert np.allclose(s[0, :3], [2.97965075, -7.73765166, -77.20524113], atol=1e-7)
+    fr = {"type": "frplda", "mu": rng.randn(d), "B": W, "W": 2 * W}
+    assert np.allclose(O.llr_1vs1(fr, x[::2], x[1::2])[0, :2], [28.60123297, 1.69248982], atol=1e-7)
+    pl = {"type": "plda", "mu": rng.randn(d), "V": V, "U": rng.randn(3, d), "D": np.abs(rng.randn(d)) + 1}
+    assert np.allclose(O.llr_1vs1(pl, x[::2], x[1::2])[0, :2], [2.50270301, -8.85197729], atol=1e-7)
+    sc, ct, ec = rng.randn(6, 7), rng.randn(30, 7), rng.randn(6, 30)
+    assert np.allclose(O.adapt_s_norm(sc, ct, ec, nbest=10)[0, :3],
+                       [1.04342288, 0.54618728, -1.02196569], atol=1e-7)
+
+
+def test_transforms(golden):
+    g = golden("transforms")
+    x = g["x"]
+    close(O.cent_whiten_predict(x, g["mu1"], g["T1"]), g["cw"])
+    close(O.cent_whiten_predict(x, g["mu1"], None), g["cw_noT"])
+    close(O.cent_whiten_predict(x, None, g["T1"]), g["cw_nomu"])
+    close(O.lnorm_predict(x, g["mu1"], g["T1"]), g["lnorm"])
+    close(O.lnorm_predict(x), g["lnorm_plain"])
+    close(O.lda_predict(x, g["mu3"], g["T3"]), g["lda"])
+    close(O.lda_predict(x, g["mu3"], g["T3"]), g["pca"])
+    close(O.lda_predict(x, None, g["T3"]), g["pca_nomu"])
+    close(O.chain_predict(x, [("lda", g["mu3"], g["T3"]), ("lnorm", None, None)]), g["chain_lda_lnorm"])
+    close(O.chain_predict(x, [("cw", g["mu1"], g["T1"]), ("lnorm", None, None),
+                              ("lda", g["mu2"], g["T2"])]), g["chain_cw_lnorm_lda"])
+    close(O.chain_predict(x, [("pca", g["mu1"], g["T1"]), ("lnorm", g["mu2"], None),
+                              ("lda", g["mu2"], g["T2"]), ("lnorm", None, None)]), g["chain_two_norms"])
+    close(O.lnorm_predict(g["x_zero_row"]), g["lnorm_zero_row"])
+
+
+@pytest.mark.parametrize("kind", ["splda", "frplda", "plda"])
+@pytest.mark.parametrize("method", ["book", "vavg", "vavg-lnorm", "savg"])
+def test_nvsm(golden, kind, method):
+    g = golden("llr_NvsM")
+    m = model_from(g, kind + "_", kind)
+    key = method.replace("-", "_")
+    close(O.llr_NvsM(m, g["x1"], g["x2"], g["ids1"], g["ids2"], method), g["%s_NvsM_%s" % (kind, key)])
+    close(O.llr_Nvs1(m, g["x1"], g["x2"], g["ids1"], method), g["%s_Nvs1_%s" % (kind, key)])
+
+
+def test_stats_hard(golden):
+    g = golden("llr_NvsM")
+    N, F, _ = O.compute_stats_hard(g["stats_x"], g["stats_ids"])
+    close(N, g["stats_N"])
+    close(F, g["stats_F"])
+    assert N[2] == 0  # class id 2 never occurs
+
+
+def test_score_norm(golden):
+    g = golden("score_norm")
+    sc, ct, ec = g["scores"], g["coh_test"], g["enr_coh"]
+    close(O.adapt_s_norm(sc, ct, ec, 10, 0), g["asnorm_n10"])
+    close(O.adapt_s_norm(sc, ct, ec, 20, 3), g["asnorm_n20d3"])
+    close(O.adapt_s_norm(sc, ct, ec, 100, 0), g["asnorm_clamp"])
+    close(O.adapt_s_norm(sc, ct, ec, 100, 60), g["asnorm_clampd"])
+    close(O.adapt_s_norm(sc, ct, ec, 10, 0, g["mask_coh_test"], g["mask_enr_coh"]), g["asnorm_masked"])
+    close(O.s_norm(sc, ct, ec), g["snorm"])
+    close(O.s_norm(sc, ct, ec, g["mask_coh_test"], g["mask_enr_coh"]), g["snorm_masked"])
+    close(O.t_norm(sc, ct), g["tnorm"])
+    close(O.z_norm(sc, ec), g["znorm"])
+    close(O.z_norm(sc, g["enr_coh_const"]), g["znorm_floor"])
+    close(O.adapt_s_norm(sc, ct, g["enr_coh_const"], 10, 0), g["asnorm_floor"])
+
+
+def test_metrics_and_math(golden):
+    g = golden("metrics_math")
+    # the reference's own unit-test inputs and bounds (tests/hyperion/metrics/test_eer.py:14-29,
+    # test_dcf.py:14-44)
+    tar = np.linspace(-2, 10, 1000) + 3
+    non = np.linspace(-10, 2, 1000) + 3
+    eer = O.compute_eer(tar, non)
+    assert 0.166 < eer < 0.167
+    close(eer, g["lin_eer"])
+    dcf = O.compute_min_dcf(tar, non, 0.5)[0]
+    assert 0.332 < dcf < 0.334
+    close(dcf, g["lin_min_dcf"])
+    close(O.compute_eer(g["tar"], g["non"]), g["eer"])
+    close(O.compute_min_dcf(g["tar"], g["non"], 0.05)[0], g["min_dcf_005"])
+    close(O.compute_min_dcf(g["tar"], g["non"], 0.01)[0], g["min_dcf_001"])
+    close(O.logdet_pdmat(g["pd_A"]), g["pd_logdet"])
+    close(O.inv_pdmat(g["pd_A"]), g["pd_inv"])
+    close(O.right_solve_upper(g["tri_R"], g["pd_X"]), g["tri_XiR"])
+    # same pins as the reference's tests/hyperion/utils/test_math.py: against scipy inv / det
+    assert np.allclose(O.inv_pdmat(g["pd_A"]), np.linalg.inv(g["pd_A"]))
+    assert np.allclose(O.logdet_pdmat(g["pd_A"]), np.log(np.linalg.det(g["pd_A"])))
+
+
+def test_medium(golden):
+    g = golden("splda_medium")
+    m = model_from(g, "m_", "splda")
+    s = O.llr_1vs1(m, g["x1"].astype(float), g["x2"].astype(float))
+    close(s, g["scores"])
+    # the calibrated synthetic model has scores on both sides of zero
+    assert (s > 0).any() and (s < 0).any()
