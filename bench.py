@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""Benchmark of the PLDA back-end scoring hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload chain_splda_100k|...]
+
+One "step" = one pass of the hot path over one batch of synthetic x-vectors that are already
+resident in HBM: embedding prologue (pre-processing chain + PLDA projection) for the enrol and the
+test side, then the full trial score matrix (kept on the device).  With N > 1 every rank scores the
+same enrol set against its own shard of test vectors (row-wise test sharding, no data-path
+collective): per-GPU work is fixed, so scaling is "weak" and the reported value is the number of
+scores all ranks produced divided by the slowest rank's time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (256 CU x 256 flop/clk x 2.4 GHz)
+HBM_PEAK_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (n_enrol, n_test per GPU, d_in, lda_dim, K)
+    "chain_splda_100k": dict(n_enrol=100_000, n_test=100_000, d=512, lda=200, K=150),
+    "chain_splda_20k": dict(n_enrol=20_000, n_test=20_000, d=512, lda=200, K=150),
+    "splda_vox1": dict(n_enrol=4874, n_test=4874, d=512, lda=None, K=150),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="chain_splda_100k", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=20000,
+                    help="rows/cols of the square slice the CPU baseline is timed on")
+    return ap.parse_args()
+
+
+def build_workload(cfg):
+    """Host-side synthetic model + chain (float64 parameters)."""
+    import synth
+
+    if cfg["lda"] is None:
+        return None, synth.make_splda(cfg["d"], cfg["K"])
+    chain = synth.chain_cfg2(d=cfg["d"], lda_dim=cfg["lda"])
+    return chain, synth.make_splda(cfg["lda"], cfg["K"])
+
+
+def make_inputs(cfg, n, seed):
+    import synth
+
+    if cfg["lda"] is None:
+        m = synth.make_splda(cfg["d"], cfg["K"])
+        per = 122
+        x = synth.length_norm(synth.sample_splda(m, (n + per - 1) // per, per, seed))[:n]
+        return x.astype(np.float32)
+    x, _ = synth.raw_xvectors(n, d=cfg["d"], seed=seed)
+    return x.astype(np.float32)
+
+
+def cpu_baseline(cfg, chain, model, sample):
+    """The float64 numpy oracle (same operation sequence as the reference) timed on a bounded
+    square slice of the same workload."""
+    from oracle import plda_ref as O
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count()
+    n = min(sample, cfg["n_enrol"], cfg["n_test"])
+    x1 = make_inputs(cfg, n, 31).astype(np.float64)
+    x2 = make_inputs(cfg, n, 32).astype(np.float64)
+    t0 = time.perf_counter()
+    if chain is not None:
+        y1, y2 = O.chain_predict(x1, chain), O.chain_predict(x2, chain)
+    else:
+        y1, y2 = x1, x2
+    s = O.llr_1vs1(model, y1, y2)
+    dt = time.perf_counter() - t0
+    del s
+    return {"value": n * n / dt, "unit": "scores/s", "cores": int(cores), "kind": "port",
+            "sample": "%d x %d trials (chain on 2 x %d vectors + SPLDA llr_1vs1), float64 numpy, %.2f s"
+                      % (n, n, n, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    from hyperion_amd import engine
+    from hyperion_amd.engine import SIDE_ENROL, SIDE_TEST
+    from hyperion_amd.pdfs.plda import SPLDA
+    from hyperion_amd.transforms import LDA, CentWhiten, LNorm, TransformList
+
+    cfg = WORKLOADS[args.workload]
+    chain, model = build_workload(cfg)
+    plda = SPLDA(mu=model["mu"], V=model["V"], W=model["W"])
+    preproc = None
+    if chain is not None:
+        preproc = TransformList([CentWhiten(mu=chain[0][1], T=chain[0][2], name="cw"), LNorm(name="ln"),
+                                 LDA(mu=chain[2][1], T=chain[2][2], name="lda")])
+    plan = plda.score_plan(preproc)
+
+    n1, n2 = cfg["n_enrol"], cfg["n_test"]
+    x1_h = make_inputs(cfg, n1, 21)
+    x2_h = make_inputs(cfg, n2, 22 + 1000 * rank)  # every rank owns a different test shard
+    x1 = engine.upload(x1_h)
+    x2 = engine.upload(x2_h)
+    ldo = engine.round_up(n2, 32)
+    S = torch.empty((n1, ldo), dtype=torch.float32, device="cuda")[:, :n2]
+    torch.cuda.synchronize()
+
+    ev_pairs = []
+
+    def step(record):
+        G1 = plan.prologue(x1, SIDE_ENROL)
+        G2 = plan.prologue(x2, SIDE_TEST)
+        if record:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            engine.score(G1, G2, out=S)
+            e1.record()
+            ev_pairs.append((e0, e1))
+        else:
+            engine.score(G1, G2, out=S)
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    score_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs]))
+    scores_per_step = float(n1) * float(n2) * world
+    value = scores_per_step * args.steps / dt
+    K = cfg["K"]
+    achieved_tflops = 2.0 * K * n1 * n2 / (score_ms * 1e-3) / 1e12
+
+    out = {
+        "metric": "PLDA trial scores/sec (512-d, SPLDA)",
+        "value": value,
+        "unit": "scores/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s: CentWhiten(512x512)+LNorm+LDA(%s)+SPLDA(y_dim %d) prologue on %d enrol + %d "
+                        "test 512-d x-vectors, full %d x %d score matrix per GPU, no score normalisation"
+                        % (args.workload, cfg["lda"], K, n1, n2, n1, n2),
+            "n_enrol": n1, "n_test_per_gpu": n2, "x_dim": cfg["d"], "lda_dim": cfg["lda"], "y_dim": K,
+            "parallelism": "test rows sharded over %d GPU(s), enrol replicated" % world,
+        },
+        "roofline": {
+            "kernel": "score_rs_kernel<%d,2>" % plan.kp,
+            "bound": "mfma",
+            "achieved": achieved_tflops,
+            "peak": FP32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved_tflops / FP32_MFMA_PEAK_TFLOPS,
+            "traffic": None,
+            "avg_launch_ms": score_ms,
+            "algorithmic_flops_per_launch": 2.0 * K * n1 * n2,
+        },
+    }
+
+    if rank == 0 and not args.no_check:
+        # parity spot check outside the timed region: a slab of the device matrix vs the oracle
+        from oracle import plda_ref as O
+
+        r, c = min(16, n1), min(4096, n2)
+        y1 = x1_h[:r].astype(np.float64)
+        y2 = x2_h[:c].astype(np.float64)
+        if chain is not None:
+            y1, y2 = O.chain_predict(y1, chain), O.chain_predict(y2, chain)
+        ref = O.llr_1vs1(model, y1, y2)
+        got = S[:r, :c].cpu().numpy().astype(np.float64)
+        err = np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)
+        out["parity"] = {"max_err_over_max_abs_1": float(err.max()), "slab": [r, c],
+                         "checksum": float(S.sum(dtype=torch.float64).item())}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, chain, model, args.cpu_sample)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

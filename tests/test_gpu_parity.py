@@ -1,0 +1,302 @@
+"""GPU parity: the HIP path (through the C ABI, via the host classes) against the reference's
+golden outputs and against the CPU oracle on seeded inputs.
+
+Tolerance.  The device computes in fp32 with fp32 MFMA accumulation, the reference in float64.
+The bar written here is  |s_gpu - s_ref| <= 1e-4 * max(|s_ref|, 1)  per score: 1e-4 relative for
+every score of magnitude >= 1 and 1e-4 absolute below that (fp32 accumulation over K terms cannot
+give a relative bound for scores that cancel to ~0).  Decision metrics (EER, minDCF) must be
+identical."""
+import numpy as np
+import pytest
+
+from conftest import model_from
+from oracle import plda_ref as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def assert_scores(got, ref, rtol=RTOL):
+    got, ref = np.asarray(got, float), np.asarray(ref, float)
+    assert got.shape == ref.shape
+    assert got.dtype == np.float64
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    err = np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)
+    assert np.nanmax(err) <= rtol if err.size else True, float(np.nanmax(err))
+
+
+def make(kind, m):
+    from hyperion_amd.pdfs.plda import FRPLDA, PLDA, SPLDA
+
+    if kind == "splda":
+        return SPLDA(mu=m["mu"], V=m["V"], W=m["W"])
+    if kind == "frplda":
+        return FRPLDA(mu=m["mu"], B=m["B"], W=m["W"])
+    return PLDA(mu=m["mu"], V=m["V"], U=m["U"], D=m["D"])
+
+
+@pytest.mark.parametrize("kind", ["splda", "frplda", "plda"])
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_llr_1vs1_golden(golden, kind, tag):
+    g = golden("llr_1vs1")
+    m = model_from(g, "%s_%s_" % (kind, tag), kind)
+    s = make(kind, m).llr_1vs1(g["x1_" + tag], g["x2_" + tag])
+    assert_scores(s, g["%s_%s_scores" % (kind, tag)])
+
+
+def test_splda_medium_golden_and_metrics(golden):
+    g = golden("splda_medium")
+    m = model_from(g, "m_", "splda")
+    s = make("splda", m).llr_1vs1(g["x1"], g["x2"])
+    ref = g["scores"]
+    assert_scores(s, ref)
+    # rows/cols come from 32 classes x 8: x1 = even rows, x2 = odd rows of the same ordering
+    cls1 = (np.arange(96) * 2) // 8
+    cls2 = (np.arange(ref.shape[1]) * 2 + 1) // 8
+    key = cls1[:, None] == cls2[None, :]
+    assert O.compute_eer(s[key], s[~key]) == O.compute_eer(ref[key], ref[~key])
+    assert O.compute_min_dcf(s[key], s[~key], 0.05)[0] == O.compute_min_dcf(ref[key], ref[~key], 0.05)[0]
+
+
+def test_transforms_golden(golden):
+    from hyperion_amd.transforms import LDA, PCA, CentWhiten, LNorm, TransformList
+
+    g = golden("transforms")
+    x = g["x"]
+
+    def chk(y, key, tol=2e-6):
+        ref = g[key]
+        assert y.dtype == np.float64 and y.shape == ref.shape
+        assert np.max(np.abs(y - ref)) <= tol * max(1.0, np.max(np.abs(ref))), key
+
+    chk(CentWhiten(mu=g["mu1"], T=g["T1"]).predict(x), "cw")
+    chk(CentWhiten(mu=g["mu1"], T=None).predict(x), "cw_noT")
+    chk(CentWhiten(mu=None, T=g["T1"]).predict(x), "cw_nomu")
+    chk(LNorm(mu=g["mu1"], T=g["T1"]).predict(x), "lnorm")
+    chk(LNorm().predict(x), "lnorm_plain")
+    chk(LDA(mu=g["mu3"], T=g["T3"]).predict(x), "lda")
+    chk(PCA(mu=g["mu3"], T=g["T3"]).predict(x), "pca")
+    chk(PCA(mu=None, T=g["T3"]).predict(x), "pca_nomu")
+    chk(TransformList([LDA(mu=g["mu3"], T=g["T3"], name="lda"), LNorm(name="ln")]).predict(x),
+        "chain_lda_lnorm")
+    chk(TransformList([CentWhiten(mu=g["mu1"], T=g["T1"], name="cw"), LNorm(name="ln"),
+                       LDA(mu=g["mu2"], T=g["T2"], name="lda")]).predict(x), "chain_cw_lnorm_lda")
+    chk(TransformList([PCA(mu=g["mu1"], T=g["T1"], name="pca"), LNorm(mu=g["mu2"], T=None, name="l1"),
+                       LDA(mu=g["mu2"], T=g["T2"], name="lda"), LNorm(name="l2")]).predict(x),
+        "chain_two_norms")
+    chk(LNorm().predict(g["x_zero_row"]), "lnorm_zero_row")
+    # 1-D T: the reference raises NameError here; the element-wise product is the evident intent
+    d = np.linspace(0.5, 2.0, x.shape[1])
+    y = CentWhiten(mu=g["mu1"], T=d).predict(x)
+    assert np.max(np.abs(y - (x - g["mu1"]) * d)) <= 2e-6 * np.max(np.abs(y))
+    # the input is not modified
+    x0 = x.copy()
+    LNorm().predict(x)
+    assert np.array_equal(x, x0)
+
+
+@pytest.mark.parametrize("kind", ["splda", "frplda", "plda"])
+@pytest.mark.parametrize("method", ["book", "vavg", "vavg-lnorm", "savg"])
+def test_nvsm_golden(golden, kind, method):
+    g = golden("llr_NvsM")
+    model = make(kind, model_from(g, kind + "_", kind))
+    key = method.replace("-", "_")
+    s = model.llr_NvsM(g["x1"], g["x2"], ids1=g["ids1"], ids2=g["ids2"], method=method)
+    assert_scores(s, g["%s_NvsM_%s" % (kind, key)])
+    s = model.llr_Nvs1(g["x1"], g["x2"], ids1=g["ids1"], method=method)
+    assert_scores(s, g["%s_Nvs1_%s" % (kind, key)])
+
+
+@pytest.mark.parametrize("kind", ["splda", "frplda"])
+def test_nvsm_from_stats(golden, kind):
+    """ids=None: the first arguments already are (N, F, S) statistics; F must not be modified."""
+    g = golden("llr_NvsM")
+    model = make(kind, model_from(g, kind + "_", kind))
+    N1, F1, _ = O.compute_stats_hard(g["x1"], g["ids1"])
+    N2, F2, _ = O.compute_stats_hard(g["x2"], g["ids2"])
+    F1c = F1.copy()
+    for method in ["book", "vavg", "vavg-lnorm"]:
+        s = model.llr_NvsM((N1, F1, None), (N2, F2, None), method=method)
+        assert_scores(s, g["%s_NvsM_%s" % (kind, method.replace("-", "_"))])
+    assert np.array_equal(F1, F1c)
+
+
+def test_compute_stats_hard(golden):
+    from hyperion_amd.pdfs.plda import SPLDA
+
+    g = golden("llr_NvsM")
+    N, F, S = SPLDA.compute_stats_hard(g["stats_x"], g["stats_ids"])
+    assert np.array_equal(N, g["stats_N"])
+    assert np.max(np.abs(F - g["stats_F"])) <= 1e-6 * np.max(np.abs(g["stats_F"]))
+    assert N[2] == 0 and np.all(F[2] == 0)  # a class id that never occurs
+
+
+def test_missing_class_gives_nan(golden):
+    """An enrolment id that never occurs: N = 0 and the class mean is 0/0.  The reference then
+    fails inside scipy (solve_triangular rejects non-finite input with ValueError); this
+    implementation returns a NaN row for that class and correct scores for all others."""
+    g = golden("llr_NvsM")
+    m = model_from(g, "splda_", "splda")
+    ids1 = g["ids1"].copy()
+    ids1[ids1 == 2] = 8  # class 2 disappears, class 8 appears
+    with pytest.raises(ValueError), np.errstate(all="ignore"):
+        O.llr_NvsM(m, g["x1"], g["x2"], ids1, g["ids2"], "vavg")
+    s = make("splda", m).llr_NvsM(g["x1"], g["x2"], ids1=ids1, ids2=g["ids2"], method="vavg")
+    assert s.shape[0] == 9 and np.all(np.isnan(s[2]))
+    # the other classes: same as scoring with contiguous ids (class 8 renamed back to 2)
+    ref = O.llr_NvsM(m, g["x1"], g["x2"], g["ids1"], g["ids2"], "vavg")
+    assert_scores(s[[0, 1, 3, 4, 5, 6, 7]], ref[[0, 1, 3, 4, 5, 6, 7]])
+    assert_scores(s[8:9], ref[2:3])
+
+
+def test_score_norm_golden(golden):
+    from hyperion_amd.score_norm import AdaptSNorm, SNorm, TNorm, ZNorm
+
+    g = golden("score_norm")
+    sc, ct, ec = g["scores"], g["coh_test"], g["enr_coh"]
+    keep = [a.copy() for a in (sc, ct, ec)]
+
+    def chk(y, key, tol=2e-5):
+        ref = g[key]
+        assert y.dtype == np.float64 and y.shape == ref.shape
+        err = np.abs(y - ref) / np.maximum(np.abs(ref), 1.0)
+        assert err.max() <= tol, (key, err.max())
+
+    chk(AdaptSNorm(nbest=10).predict(sc, ct, ec), "asnorm_n10")
+    chk(AdaptSNorm(nbest=20, nbest_discard=3).predict(sc, ct, ec), "asnorm_n20d3")
+    chk(AdaptSNorm(nbest=100).predict(sc, ct, ec), "asnorm_clamp")
+    chk(AdaptSNorm(nbest=100, nbest_discard=60).predict(sc, ct, ec), "asnorm_clampd")
+    chk(SNorm().predict(sc, ct, ec), "snorm")
+    chk(SNorm().predict(sc, ct, ec, g["mask_coh_test"], g["mask_enr_coh"]), "snorm_masked")
+    chk(TNorm().predict(sc, ct), "tnorm")
+    chk(ZNorm().predict(sc, ec), "znorm")
+    # constant cohort: std 0 -> floor 1e-5, so the output is 1e5 * (s - 1.5): the fp32 rounding of
+    # the input score s (6e-8 relative) is amplified wherever s is close to the cohort mean
+    chk(ZNorm().predict(sc, g["enr_coh_const"]), "znorm_floor", tol=1e-3)
+    chk(AdaptSNorm(nbest=10).predict(sc, ct, g["enr_coh_const"]), "asnorm_floor", tol=1e-3)
+    for a, b in zip((sc, ct, ec), keep):
+        assert np.array_equal(a, b)  # caller arrays untouched
+
+
+def test_adapt_s_norm_masked():
+    """Masked cohort entries count as zero when ranking and are excluded from the moments.  The
+    cohort scores are positive here so that the zeros rank last and no tie straddles the top-k
+    boundary (numpy's order among ties is unspecified)."""
+    from hyperion_amd.score_norm import AdaptSNorm
+
+    rng = np.random.RandomState(5)
+    ne, nt, nc = 9, 14, 50
+    sc = rng.randn(ne, nt) * 5
+    ct = rng.rand(nc, nt) * 4 + 2
+    ec = rng.rand(ne, nc) * 4 + 2
+    mct = rng.rand(nc, nt) > 0.3
+    mec = rng.rand(ne, nc) > 0.3
+    ref = O.adapt_s_norm(sc, ct, ec, 8, 0, mct, mec)
+    got = AdaptSNorm(nbest=8).predict(sc, ct, ec, mct, mec)
+    err = np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)
+    assert err.max() <= 2e-5
+
+
+def test_adapt_s_norm_vs_oracle_large():
+    """A cohort large enough to exercise several radix passes and many lists per row."""
+    from hyperion_amd.score_norm import AdaptSNorm
+
+    rng = np.random.RandomState(9)
+    ne, nt, nc = 70, 333, 3000
+    sc = rng.randn(ne, nt) * 6 - 5
+    ct = (rng.randn(nc, nt) * 8 - 14).astype(np.float32).astype(float)
+    ec = (rng.randn(ne, nc) * 8 - 14).astype(np.float32).astype(float)
+    for nbest, disc in [(300, 0), (200, 17)]:
+        ref = O.adapt_s_norm(sc, ct, ec, nbest, disc)
+        got = AdaptSNorm(nbest=nbest, nbest_discard=disc).predict(sc, ct, ec)
+        err = np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)
+        assert err.max() <= 2e-5, err.max()
+
+
+def test_topk_ties_and_duplicates():
+    """Exact ties: the selected set must have the right size and every selected value must be >=
+    every unselected one; ties at the boundary go to the lower index."""
+    import torch
+
+    from hyperion_amd.score_norm.adapt_s_norm import topk_rows
+
+    rng = np.random.RandomState(3)
+    A = rng.randint(0, 6, size=(37, 500)).astype(np.float32)  # heavy ties
+    A[5] = 1.0
+    for k, disc in [(50, 0), (17, 9), (500, 0), (1, 499)]:
+        idx = topk_rows(torch.from_numpy(A).cuda(), k, disc).cpu().numpy()[:, :37].T  # [rows, k]
+        for r in range(A.shape[0]):
+            order = np.lexsort((np.arange(500), -A[r]))  # descending value, ascending index
+            want = np.sort(order[disc:disc + k])
+            assert np.array_equal(idx[r], want), (k, disc, r)
+
+
+@pytest.mark.parametrize("n1,n2", [(0, 5), (5, 0), (1, 1), (1, 33), (257, 31), (129, 65), (300, 1000)])
+def test_ragged_shapes(n1, n2):
+    import synth
+
+    m = synth.make_splda(48, 10)
+    x = synth.length_norm(synth.sample_splda(m, 200, 8, seed=3))
+    x1, x2 = x[:n1], x[1600 - n2:1600]
+    s = make("splda", m).llr_1vs1(x1, x2)
+    assert s.shape == (n1, n2)
+    if n1 and n2:
+        assert_scores(s, O.llr_1vs1(m, x1, x2))
+
+
+@pytest.mark.parametrize("d,K", [(30, 5), (64, 62), (150, 100), (200, 150), (320, 180), (330, 250)])
+def test_packed_widths(d, K):
+    """Every register-stationary width and the K-loop kernel (wide models)."""
+    import synth
+
+    m = synth.make_splda(d, K)
+    x = synth.length_norm(synth.sample_splda(m, 40, 6, seed=2))
+    s = make("splda", m).llr_1vs1(x[:150], x[80:])
+    assert_scores(s, O.llr_1vs1(m, x[:150], x[80:]))
+
+
+def test_frplda_wide():
+    """FRPLDA has K = x_dim: 400 dims exceeds the register-stationary widths."""
+    import synth
+
+    m = synth.make_frplda(400, 60)
+    xs = synth.length_norm(synth.sample_splda(synth.make_splda(400, 60), 20, 5, seed=4))
+    s = make("frplda", m).llr_1vs1(xs[:60], xs[40:])
+    assert_scores(s, O.llr_1vs1(m, xs[:60], xs[40:]))
+
+
+def test_fused_preproc_equals_two_step(golden):
+    """llr_1vs1(x, preproc=chain) == llr_1vs1(chain.predict(x)) == oracle."""
+    import synth
+    from hyperion_amd.transforms import LDA, CentWhiten, LNorm, TransformList
+
+    chain = synth.chain_cfg2(d=96, lda_dim=40, seed=3)
+    m = synth.make_splda(40, 12)
+    x1, _ = synth.raw_xvectors(70, d=96, seed=21, num_centers=30)
+    x2, _ = synth.raw_xvectors(90, d=96, seed=22, num_centers=30)
+    tl = TransformList([CentWhiten(mu=chain[0][1], T=chain[0][2], name="cw"), LNorm(name="ln"),
+                        LDA(mu=chain[2][1], T=chain[2][2], name="lda")])
+    model = make("splda", m)
+    ref = O.llr_1vs1(m, O.chain_predict(x1, chain), O.chain_predict(x2, chain))
+    assert_scores(model.llr_1vs1(x1, x2, preproc=tl), ref)
+    assert_scores(model.llr_1vs1(tl.predict(x1), tl.predict(x2)), ref)
+
+
+def test_voxceleb_size_full_matrix():
+    """Config 1: 4874 x 4874 SPLDA scores, 512-d, y_dim 150, against the oracle (full matrix),
+    plus EER / minDCF identity on the sub-sampled trial lists."""
+    import synth
+
+    m, x, cls = synth.voxceleb_like()
+    s = make("splda", m).llr_1vs1(x, x)
+    ref = O.llr_1vs1(m, x, x)
+    err = np.abs(s - ref) / np.maximum(np.abs(ref), 1.0)
+    assert err.max() <= RTOL, err.max()
+    key = cls[:, None] == cls[None, :]
+    tar_g, non_g = s[key][::20], s[~key][::100]
+    tar_r, non_r = ref[key][::20], ref[~key][::100]
+    assert O.compute_eer(tar_g, non_g) == O.compute_eer(tar_r, non_r)
+    assert O.compute_min_dcf(tar_g, non_g, 0.05)[0] == O.compute_min_dcf(tar_r, non_r, 0.05)[0]
+    # size-independent property: the matrix of a set against itself is symmetric up to rounding
+    assert np.max(np.abs(s - s.T)) <= 2e-4
