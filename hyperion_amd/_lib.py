@@ -70,6 +70,7 @@ SIGNATURES = {
     "hypmi_scatter_block": (ctypes.c_int, [c_void_p, i64, c_void_p, i64, c_void_p, i64, c_void_p, i64,
                                            c_void_p]),
     "hypmi_topk_workspace_bytes": (i64, [i64, ctypes.c_int]),
+    "hypmi_topk_list_bytes": (i64, [ctypes.c_int, i64]),
     "hypmi_topk_rows": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, i64, ctypes.c_int, ctypes.c_int,
                                        c_void_p, i64, c_void_p, i64, c_void_p]),
     "hypmi_gather_stats": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, i64, c_void_p, i64, c_void_p,

@@ -1,0 +1,126 @@
+"""Device-resident back-end: pre-processing chain -> PLDA scores -> adaptive S-norm for large trial
+matrices, with test vectors sharded over the GPUs of a node.
+
+This is the flow of the reference's evaluation scripts (egs/voices_challenge/v1/steps_be/
+eval-be-snorm-v1.py:28-91: llr_1vs1 on trials, cohort-vs-test and enrol-vs-cohort, then
+AdaptSNorm.predict) kept on the device end to end: cohort score panels never leave HBM, test
+vectors are processed in chunks so that the [test, cohort] panel stays bounded, and the enrol-side
+top-k lists are the only thing exchanged between GPUs.
+
+Sharding follows the reference's job grid (hyperion/utils/list_utils.py:95-112 `split_list`,
+used by TrialNdx.split, hyperion/utils/trial_ndx.py:252-268): part i of n owns the contiguous
+range [floor((i-1) N / n), floor(i N / n)).
+"""
+import numpy as np
+
+from . import engine
+from .engine import SIDE_ENROL, SIDE_TEST
+from .score_norm.adapt_s_norm import gather_stats, topk_rows
+
+
+def shard_range(n, part, num_parts):
+    """Rows owned by `part` (0-based) of `num_parts`: the contiguous floor partition of
+    split_list (1-based idx there)."""
+    lo = int(np.floor(part * float(n) / num_parts))
+    hi = int(np.floor((part + 1) * float(n) / num_parts))
+    return lo, hi
+
+
+def all_gather_lists(local, counts, group=None):
+    """All-gather of per-rank top-k lists [G, rows_of_rank * w] (w entries per row and group, rows
+    contiguous) into [G, sum(rows) * w]; `counts[r]` is the width rank r contributes.  One collective;
+    with a single rank (or no process group) the input is returned unchanged."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    assert len(counts) == world
+    k = local.shape[0]
+    width = max(counts)
+    send = torch.zeros((k, width), dtype=local.dtype, device=local.device)
+    send[:, :local.shape[1]] = local
+    recv = torch.empty((world * k, width), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    recv = recv.view(world, k, width)
+    return torch.cat([recv[r, :, :counts[r]] for r in range(world)], dim=1).contiguous()
+
+
+class PLDABackend:
+    """plda: a hyperion_amd SPLDA / FRPLDA / PLDA; preproc: optional TransformList folded into the
+    embedding prologue; nbest / nbest_discard: adaptive S-norm cohort selection."""
+
+    def __init__(self, plda, preproc=None, nbest=300, nbest_discard=0, test_chunk=65536):
+        self.plda = plda
+        self.plan = plda.score_plan(preproc)
+        self.nbest = int(nbest)
+        self.nbest_discard = int(nbest_discard)
+        self.test_chunk = int(test_chunk)
+
+    # ---- embeddings ---------------------------------------------------------------------------
+    def embed(self, x, side):
+        """Raw vectors (numpy or device tensor) -> packed device rows for one side of a trial."""
+        return self.plan.prologue(engine.upload(x), side)
+
+    def score(self, x_enrol, x_test, out=None):
+        """Raw PLDA log-likelihood ratios, device [n_enrol, n_test]."""
+        return engine.score(self.embed(x_enrol, SIDE_ENROL), self.embed(x_test, SIDE_TEST), out=out)
+
+    # ---- scoring with adaptive S-norm -----------------------------------------------------------
+    def prepare_cohort(self, x_enrol, x_cohort, rank=0, world=1, group=None):
+        """Everything that depends only on enrolment and cohort: packed rows, the enrol-vs-cohort
+        panel A_ec [n_enrol, n_cohort] and the per-enrolment top-k cohort lists.  With world > 1 each
+        rank selects the lists of its own slice of enrolment rows and one all-gather makes them
+        global (the only inter-GPU exchange of the whole pipeline)."""
+        Ge = self.embed(x_enrol, SIDE_ENROL)
+        xc = engine.upload(x_cohort)
+        Gc_test = self.plan.prologue(xc, SIDE_TEST)
+        A_ec = engine.score(Ge, Gc_test)
+        ne, nc = A_ec.shape
+        assert self.nbest_discard < nc
+        k = min(self.nbest, nc - self.nbest_discard)
+        counts = [8 * (shard_range(ne, r, world)[1] - shard_range(ne, r, world)[0]) for r in range(world)]
+        lo, hi = shard_range(ne, rank, world)
+        local = topk_rows(A_ec[lo:hi], k, self.nbest_discard)[:, :hi - lo]  # [k/8, rows, 8]
+        e_idx = all_gather_lists(local.reshape(local.shape[0], -1), counts, group)
+        e_idx = e_idx.reshape(e_idx.shape[0], -1, 8).contiguous()
+        return {"Ge": Ge, "Gc_test": Gc_test, "A_ec": A_ec, "e_idx": e_idx, "k": k}
+
+    def score_snorm(self, x_test, cohort, out=None, reduce=None):
+        """AS-normalised scores of every enrolment model against `x_test` (this rank's shard).
+        cohort: result of prepare_cohort.  Returns a device [n_enrol, n_test] tensor, or, when
+        `reduce` is given, calls reduce(col0, block) on every [n_enrol, chunk] block instead of
+        keeping the matrix (for trial sets whose score matrix does not fit)."""
+        from . import _lib
+
+        torch = engine.require_gpu()
+        lib = _lib.load()
+        xt = engine.upload(x_test)
+        nt = xt.shape[0]
+        Ge, A_ec, e_idx, k = cohort["Ge"], cohort["A_ec"], cohort["e_idx"], cohort["k"]
+        ne = Ge.shape[0]
+        if out is None and reduce is None:
+            ld = engine.round_up(max(nt, 1), 32)
+            out = torch.empty((ne, ld), dtype=torch.float32, device=xt.device)[:, :nt]
+        for c0 in range(0, nt, self.test_chunk):
+            c1 = min(nt, c0 + self.test_chunk)
+            xc = xt[c0:c1]
+            Gt_rows = self.plan.prologue(xc, SIDE_ENROL)  # tests as rows of the cohort panel
+            Gt_cols = self.plan.prologue(xc, SIDE_TEST)   # tests as columns of the trial matrix
+            A_tc = engine.score(Gt_rows, cohort["Gc_test"])            # [chunk, cohort]
+            t_idx = topk_rows(A_tc, k, self.nbest_discard)             # [k, chunk]
+            mz, iz, ldz = gather_stats(A_ec, None, t_idx, c1 - c0, 1e-5, k)  # [enrol, chunk]
+            mt, it, ldt = gather_stats(A_tc, None, e_idx, ne, 1e-5, k)       # [chunk, enrol]
+            S = engine.score(Ge, Gt_cols)                              # [enrol, chunk]
+            if reduce is None:
+                dst = out[:, c0:c1]
+            else:
+                dst = torch.empty((ne, engine.round_up(c1 - c0, 32)), dtype=torch.float32,
+                                  device=xt.device)[:, :c1 - c0]
+            _lib.check(lib.hypmi_asnorm_apply(engine._ptr(S), S.stride(0), ne, c1 - c0, engine._ptr(mz),
+                                              engine._ptr(iz), ldz, engine._ptr(mt), engine._ptr(it), ldt,
+                                              engine._ptr(dst), dst.stride(0), engine.stream_ptr()))
+            if reduce is not None:
+                reduce(c0, dst)
+        return out

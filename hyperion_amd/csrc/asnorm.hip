@@ -11,8 +11,13 @@
 //   topk_rows     one workgroup per row; the row lives in LDS as order-preserving integer keys and
 //                 an 8-bit-per-pass radix select finds the boundary keys; ties at a boundary are
 //                 resolved by cohort index (lowest first), so the result is deterministic.
-//   gather_stats  one workgroup per X row held in LDS; lanes walk different lists, whose indices
-//                 are stored list-minor ([k][Q]) so that a wave's index loads are coalesced.
+//   gather_stats  one workgroup per group of R rows of X held in LDS (interleaved, so one LDS read
+//                 returns the R values of a cohort member); lanes walk different lists and reuse
+//                 every index for the R rows.
+//
+// Index lists are uint16 (cohort < 65536) in groups of eight: entry j of list q lives at
+// idx8[((j >> 3) * ldi + q) * 8 + (j & 7)], so a lane fetches eight consecutive entries of its list
+// with one 16-byte load and a wave's loads are contiguous (1 KiB).
 #include "common.h"
 
 namespace {
@@ -81,12 +86,12 @@ __device__ void select_rank(const unsigned* __restrict__ keys, int n, int want, 
     *out_gt = gt;
 }
 
-// idx_t[j * ldi + row] (j < k) = cohort indices ranked discard .. discard+k-1 of row `row`,
-// in ascending index order.
+// Writes the cohort indices ranked discard .. discard+k-1 of row `row`, in ascending index order,
+// into the grouped uint16 list layout; the unused tail of the last group of eight is zeroed.
 template <bool USE_LDS>
 __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float* __restrict__ A, int64_t lda,
                                                                int nc, int k, int discard,
-                                                               int32_t* __restrict__ idx_t, int64_t ldi,
+                                                               uint16_t* __restrict__ idx8, int64_t ldi,
                                                                unsigned* __restrict__ gkeys) {
     extern __shared__ __attribute__((aligned(16))) unsigned smem[];
     unsigned* hist = smem;          // 256
@@ -97,6 +102,10 @@ __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float* __re
     const int64_t row = blockIdx.x;
     const float* src = A + row * lda;
     for (int i = tid; i < nc; i += TK_THREADS) keys[i] = key_of(src[i]);
+    if (tid < 8 && k + tid < ((k + 7) & ~7)) {
+        const int j = k + tid;
+        idx8[((int64_t)(j >> 3) * ldi + row) * 8 + (j & 7)] = 0;
+    }
     __syncthreads();
 
     unsigned key_hi, key_lo;
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float* __re
             if (w < wave) pos += (int)wtot[2 * w];
             tot += (int)wtot[2 * w];
         }
-        if (sel && pos < k) idx_t[(int64_t)pos * ldi + row] = i;
+        if (sel && pos < k) idx8[((int64_t)(pos >> 3) * ldi + row) * 8 + (pos & 7)] = (uint16_t)i;
         written += tot;
         eq_hi_seen += hi_tot;
         eq_lo_seen += lo_tot;
@@ -164,56 +173,139 @@ __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float* __re
     }
 }
 
-// One workgroup per X row (held in LDS), lanes over lists q.
+// R rows of X per workgroup, held in LDS interleaved (xr[c * R + rr]); lanes over lists q.
 //   mean[r, q] = sum_j X[r, L[j, q]] / norm,  istd[r, q] = 1 / max(sqrt(sum x^2 / norm - mean^2), floor)
-// norm = k without mask, else the number of unmasked selected entries (mask row also in LDS).
-__global__ __launch_bounds__(256) void gather_stats_kernel(const float* __restrict__ X, int64_t ldx,
-                                                           const unsigned char* __restrict__ mask,
-                                                           int64_t ldm, int nc,
-                                                           const int32_t* __restrict__ idx_t,
-                                                           int64_t ldi, int k, int64_t Q,
-                                                           int64_t q_per_block, float floor_,
-                                                           float* __restrict__ mean,
-                                                           float* __restrict__ istd, int64_t ldo) {
-    extern __shared__ __attribute__((aligned(16))) float xrow[];
-    unsigned char* mrow = reinterpret_cast<unsigned char*>(xrow + nc);
+// Without a mask the moments are accumulated in fp32 around a per-(row, list) pivot (the list's first
+// member): the selected scores lie within a few standard deviations of each other, so the shifted
+// sums carry no cancellation, and a constant cohort gives exactly zero variance.  With a mask
+// (uint8 rows also in LDS, X already zeroed there) norm is the number of unmasked selected members
+// and the sums are kept in double.
+constexpr int GS_THREADS = 1024;
+
+template <int R>
+struct VecR;
+template <>
+struct VecR<1> { typedef float type; };
+template <>
+struct VecR<2> { typedef float2 type; };
+template <>
+struct VecR<4> { typedef float4 type; };
+
+template <int R>
+__device__ __forceinline__ void unpack(const typename VecR<R>::type& v, float (&o)[R]);
+template <>
+__device__ __forceinline__ void unpack<1>(const float& v, float (&o)[1]) { o[0] = v; }
+template <>
+__device__ __forceinline__ void unpack<2>(const float2& v, float (&o)[2]) { o[0] = v.x; o[1] = v.y; }
+template <>
+__device__ __forceinline__ void unpack<4>(const float4& v, float (&o)[4]) {
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+
+template <int R, bool MASK>
+__global__ __launch_bounds__(GS_THREADS) void gather_stats_kernel(
+    const float* __restrict__ X, int64_t ldx, int64_t n_rows, const unsigned char* __restrict__ mask,
+    int64_t ldm, int nc, const uint16_t* __restrict__ idx8, int64_t ldi, int k, int64_t Q,
+    int64_t q_per_block, float floor_, float* __restrict__ mean, float* __restrict__ istd, int64_t ldo) {
+    typedef typename VecR<R>::type vec_t;
+    extern __shared__ __attribute__((aligned(16))) float xr[];
+    unsigned char* mr = reinterpret_cast<unsigned char*>(xr + (size_t)nc * R);
     const int tid = threadIdx.x;
-    const int64_t r = blockIdx.x;
-    const float* src = X + r * ldx;
-    for (int i = tid; i < nc; i += 256) xrow[i] = src[i];
-    if (mask)
-        for (int i = tid; i < nc; i += 256) mrow[i] = mask[r * ldm + i];
+    const int64_t r0 = (int64_t)blockIdx.x * R;
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+        const bool live = r0 + rr < n_rows;
+        const float* src = X + (r0 + rr) * ldx;
+        for (int c = tid; c < nc; c += GS_THREADS) xr[c * R + rr] = live ? __builtin_nontemporal_load(src + c) : 0.f;
+        if (MASK)
+            for (int c = tid; c < nc; c += GS_THREADS) mr[c * R + rr] = live ? mask[(r0 + rr) * ldm + c] : 0;
+    }
     __syncthreads();
+    const vec_t* xv = reinterpret_cast<const vec_t*>(xr);
+    const int kg = k >> 3, krem = k & 7;
     const int64_t q0 = (int64_t)blockIdx.y * q_per_block;
     const int64_t q1 = (q0 + q_per_block < Q) ? q0 + q_per_block : Q;
-    for (int64_t q = q0 + tid; q < q1; q += 256) {
-        double s1 = 0.0, s2 = 0.0;
-        int cnt = 0;
-        const int32_t* lp = idx_t + q;
-        if (mask) {
-            for (int j = 0; j < k; ++j) {
-                const int c = lp[(int64_t)j * ldi];
-                const double v = (double)xrow[c];
-                s1 += v;
-                s2 += v * v;
-                cnt += mrow[c] ? 1 : 0;
+    for (int64_t q = q0 + tid; q < q1; q += GS_THREADS) {
+        const uint4* lp = reinterpret_cast<const uint4*>(idx8) + q;  // one uint4 = 8 entries of list q
+        float out_m[R], out_i[R];
+        if (!MASK) {
+            float piv[R], s1[R], s2[R];
+            {
+                const unsigned first = lp[0].x & 0xffffu;
+                unpack<R>(xv[first], piv);
+            }
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) s1[rr] = s2[rr] = 0.f;
+            auto add = [&](unsigned c) {
+                float v[R];
+                unpack<R>(xv[c], v);
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                    const float d = v[rr] - piv[rr];
+                    s1[rr] += d;
+                    s2[rr] = fmaf(d, d, s2[rr]);
+                }
+            };
+#pragma unroll 2
+            for (int g = 0; g < kg; ++g) {
+                const uint4 pk = lp[(int64_t)g * ldi];
+                add(pk.x & 0xffffu); add(pk.x >> 16);
+                add(pk.y & 0xffffu); add(pk.y >> 16);
+                add(pk.z & 0xffffu); add(pk.z >> 16);
+                add(pk.w & 0xffffu); add(pk.w >> 16);
+            }
+            if (krem) {
+                const uint4 pk = lp[(int64_t)kg * ldi];
+                const unsigned w[4] = {pk.x, pk.y, pk.z, pk.w};
+                for (int j = 0; j < krem; ++j) add((w[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+            }
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const double md = (double)s1[rr] / (double)k;
+                double var = (double)s2[rr] / (double)k - md * md;
+                double sd = sqrt(var > 0.0 ? var : (var == var ? 0.0 : var));
+                if (sd < (double)floor_) sd = (double)floor_;
+                out_m[rr] = (float)((double)piv[rr] + md);
+                out_i[rr] = (float)(1.0 / sd);
             }
         } else {
-#pragma unroll 4
-            for (int j = 0; j < k; ++j) {
-                const int c = lp[(int64_t)j * ldi];
-                const double v = (double)xrow[c];
-                s1 += v;
-                s2 += v * v;
+            double s1[R], s2[R];
+            int cnt[R];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                s1[rr] = s2[rr] = 0.0;
+                cnt[rr] = 0;
             }
-            cnt = k;
+            for (int j = 0; j < k; ++j) {
+                const uint4 pk = lp[(int64_t)(j >> 3) * ldi];
+                const unsigned w[4] = {pk.x, pk.y, pk.z, pk.w};
+                const unsigned c = (w[(j & 7) >> 1] >> (16 * (j & 1))) & 0xffffu;
+                float v[R];
+                unpack<R>(xv[c], v);
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                    s1[rr] += (double)v[rr];
+                    s2[rr] += (double)v[rr] * (double)v[rr];
+                    cnt[rr] += mr[c * R + rr] ? 1 : 0;
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const double m = s1[rr] / (double)cnt[rr];
+                double var = s2[rr] / (double)cnt[rr] - m * m;
+                double sd = sqrt(var > 0.0 ? var : (var == var ? 0.0 : var));  // keep NaN (0/0) visible
+                if (sd < (double)floor_) sd = (double)floor_;
+                out_m[rr] = (float)m;
+                out_i[rr] = (float)(1.0 / sd);
+            }
         }
-        const double m = s1 / (double)cnt;
-        double var = s2 / (double)cnt - m * m;
-        double sd = sqrt(var > 0.0 ? var : (var == var ? 0.0 : var));  // keep NaN (0/0) visible
-        if (sd < (double)floor_) sd = (double)floor_;
-        mean[r * ldo + q] = (float)m;
-        istd[r * ldo + q] = (float)(1.0 / sd);
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            if (r0 + rr < n_rows) {
+                mean[(r0 + rr) * ldo + q] = out_m[rr];
+                istd[(r0 + rr) * ldo + q] = out_i[rr];
+            }
+        }
     }
 }
 
@@ -350,8 +442,12 @@ extern "C" int64_t hypmi_topk_workspace_bytes(int64_t n_rows, int nc) {
     return lds_need <= MAX_LDS_BYTES ? 0 : n_rows * (int64_t)nc * 4;
 }
 
+extern "C" int64_t hypmi_topk_list_bytes(int k, int64_t ldi) {
+    return (int64_t)((k + 7) / 8) * ldi * 8 * (int64_t)sizeof(uint16_t);
+}
+
 extern "C" int hypmi_topk_rows(const float* A, int64_t n_rows, int nc, int64_t lda, int k, int discard,
-                               int32_t* idx_t, int64_t ldi, void* workspace, int64_t workspace_bytes,
+                               uint16_t* idx_t, int64_t ldi, void* workspace, int64_t workspace_bytes,
                                void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     HYPMI_REQUIRE(A && idx_t, "topk_rows: null pointer");
@@ -360,6 +456,8 @@ extern "C" int hypmi_topk_rows(const float* A, int64_t n_rows, int nc, int64_t l
                   "topk_rows: need 0 < k and discard + k <= cohort size (k=%d discard=%d nc=%d)", k,
                   discard, nc);
     HYPMI_REQUIRE(n_rows <= 0x7fffffffLL, "topk_rows: too many rows");
+    HYPMI_REQUIRE(nc <= 65536, "topk_rows: cohort of %d exceeds the 16-bit index lists", nc);
+    HYPMI_REQUIRE(aligned16(idx_t), "topk_rows: index lists must be 16-byte aligned");
     if (n_rows == 0) return HYPMI_OK;
     const int64_t lds_need = (272 + (int64_t)nc) * 4;
     if (lds_need <= MAX_LDS_BYTES) {
@@ -379,33 +477,60 @@ extern "C" int hypmi_topk_rows(const float* A, int64_t n_rows, int nc, int64_t l
     return HYPMI_OK;
 }
 
+namespace {
+template <int R, bool MASK>
+int launch_gather(const float* X, int64_t n_rows, int nc, int64_t ldx, const unsigned char* mask,
+                  int64_t ldm, const uint16_t* idx8, int64_t ldi, int k, int64_t n_lists, float std_floor,
+                  float* mean, float* istd, int64_t ldo, hipStream_t stream) {
+    const int64_t lds_need = round_up((int64_t)nc * R * 4 + (MASK ? (int64_t)nc * R : 0), 16);
+    if (lds_need > 48 * 1024)
+        HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_stats_kernel<R, MASK>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
+    const int64_t groups = (n_rows + R - 1) / R;
+    HYPMI_REQUIRE(groups <= 0x7fffffffLL, "gather_stats: too many rows");
+    // One workgroup walks all lists for its rows unless there are too few row groups to fill the chip,
+    // in which case the lists are split over blockIdx.y.  (Blocking the lists for L2 residency was
+    // measured and is slower: the kernel is bound by the random LDS gathers, not by the index stream,
+    // and every extra chunk reloads the rows into LDS.)
+    int64_t chunks = 1;
+    while (groups * chunks < 1024 && (n_lists + chunks - 1) / chunks > 4 * GS_THREADS) chunks *= 2;
+    if (chunks > 65535) chunks = 65535;
+    const int64_t q_per_block = round_up((n_lists + chunks - 1) / chunks, GS_THREADS);
+    chunks = (n_lists + q_per_block - 1) / q_per_block;
+    hipLaunchKernelGGL((gather_stats_kernel<R, MASK>), dim3((unsigned)groups, (unsigned)chunks),
+                       dim3(GS_THREADS), lds_need, stream, X, ldx, n_rows, mask, ldm, nc, idx8, ldi, k,
+                       n_lists, q_per_block, std_floor, mean, istd, ldo);
+    HYPMI_HIP(hipGetLastError());
+    return HYPMI_OK;
+}
+}  // namespace
+
 extern "C" int hypmi_gather_stats(const float* X, int64_t n_rows, int nc, int64_t ldx,
-                                  const unsigned char* mask, int64_t ldm, const int32_t* idx_t,
+                                  const unsigned char* mask, int64_t ldm, const uint16_t* idx_t,
                                   int64_t ldi, int k, int64_t n_lists, float std_floor, float* mean,
                                   float* istd, int64_t ldo, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     HYPMI_REQUIRE(X && idx_t && mean && istd, "gather_stats: null pointer");
-    HYPMI_REQUIRE(n_rows >= 0 && nc > 0 && ldx >= nc && k > 0 && n_lists >= 0 && ldi >= n_lists &&
-                      ldo >= n_lists,
+    HYPMI_REQUIRE(n_rows >= 0 && nc > 0 && nc <= 65536 && ldx >= nc && k > 0 && n_lists >= 0 &&
+                      ldi >= n_lists && ldo >= n_lists,
                   "gather_stats: bad shape");
-    HYPMI_REQUIRE(n_rows <= 0x7fffffffLL, "gather_stats: too many rows");
+    HYPMI_REQUIRE(aligned16(idx_t), "gather_stats: index lists must be 16-byte aligned");
     if (n_rows == 0 || n_lists == 0) return HYPMI_OK;
-    const int64_t lds_need = round_up((int64_t)nc * 4 + (mask ? nc : 0), 16);
-    HYPMI_REQUIRE(lds_need <= MAX_LDS_BYTES, "gather_stats: cohort of %d does not fit in LDS", nc);
-    if (lds_need > 48 * 1024)
-        HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_stats_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
-    // split the lists over blockIdx.y when there are few rows, so that the chip stays full
-    int64_t chunks = 1;
-    while (n_rows * chunks < 2048 && (n_lists + chunks - 1) / chunks > 4096) chunks *= 2;
-    if (chunks > 65535) chunks = 65535;
-    const int64_t q_per_block = round_up((n_lists + chunks - 1) / chunks, 256);
-    chunks = (n_lists + q_per_block - 1) / q_per_block;
-    hipLaunchKernelGGL(gather_stats_kernel, dim3((unsigned)n_rows, (unsigned)chunks), dim3(256), lds_need,
-                       stream, X, ldx, mask, ldm, nc, idx_t, ldi, k, n_lists, q_per_block, std_floor,
-                       mean, istd, ldo);
-    HYPMI_HIP(hipGetLastError());
-    return HYPMI_OK;
+    const int64_t per_row = (int64_t)nc * 4 + (mask ? nc : 0);
+    HYPMI_REQUIRE(per_row <= MAX_LDS_BYTES, "gather_stats: cohort of %d does not fit in LDS", nc);
+    // as many rows per workgroup as LDS holds (each index fetched is reused for all of them)
+    int R = 1;
+    if (4 * per_row <= MAX_LDS_BYTES && n_rows >= 4) R = 4;
+    else if (2 * per_row <= MAX_LDS_BYTES && n_rows >= 2) R = 2;
+#define HYPMI_GS(RR)                                                                                  \
+    return mask ? launch_gather<RR, true>(X, n_rows, nc, ldx, mask, ldm, idx_t, ldi, k, n_lists,      \
+                                          std_floor, mean, istd, ldo, stream)                         \
+                : launch_gather<RR, false>(X, n_rows, nc, ldx, mask, ldm, idx_t, ldi, k, n_lists,     \
+                                           std_floor, mean, istd, ldo, stream)
+    if (R == 4) { HYPMI_GS(4); }
+    if (R == 2) { HYPMI_GS(2); }
+    HYPMI_GS(1);
+#undef HYPMI_GS
 }
 
 extern "C" int hypmi_asnorm_apply(const float* S, int64_t lds_, int64_t ne, int64_t nt, const float* mz,

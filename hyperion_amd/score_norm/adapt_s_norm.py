@@ -6,20 +6,28 @@ from .score_norm import ScoreNorm, dev_mask, dev_matrix, transpose, transpose_ma
 
 
 def topk_rows(A, k, discard):
-    """Device [rows, cohort] -> int32 [k, rows] cohort indices ranked discard..discard+k-1 per row."""
+    """Device [rows, cohort] -> grouped uint16 index lists [ceil(k/8), rows, 8] (stored as int16):
+    entry j of row q at [j >> 3, q, j & 7]; cohort indices ranked discard..discard+k-1 per row."""
     torch = engine.require_gpu()
     lib = _lib.load()
     n, nc = A.shape
-    idx = torch.empty((k, max(n, 1)), dtype=torch.int32, device=A.device)
+    ldi = max(n, 1)
+    idx = torch.empty(((k + 7) // 8, ldi, 8), dtype=torch.int16, device=A.device)
     ws_bytes = lib.hypmi_topk_workspace_bytes(n, nc)
     ws = torch.empty(max(ws_bytes // 4, 4), dtype=torch.int32, device=A.device)
     _lib.check(lib.hypmi_topk_rows(engine._ptr(A), n, nc, A.stride(0), k, discard, engine._ptr(idx),
-                                   idx.stride(0), engine._ptr(ws), ws_bytes, engine.stream_ptr()))
+                                   ldi, engine._ptr(ws), ws_bytes, engine.stream_ptr()))
     return idx
 
 
-def gather_stats(X, mask_u8, idx, n_lists, std_floor):
-    """mean / inverse std of X[r, idx[:, q]] for every row r and list q: two device [rows, lists]."""
+def lists_to_numpy(idx, k):
+    """Grouped device lists -> host int array [rows, k] (for tests and debugging)."""
+    a = idx.cpu().numpy().view("uint16").astype("int64")  # [k8, rows, 8]
+    return a.transpose(1, 0, 2).reshape(a.shape[1], -1)[:, :k]
+
+
+def gather_stats(X, mask_u8, idx, n_lists, std_floor, k):
+    """mean / inverse std of X[r, list_q] for every row r and list q: two device [rows, lists]."""
     torch = engine.require_gpu()
     lib = _lib.load()
     n, nc = X.shape
@@ -29,7 +37,7 @@ def gather_stats(X, mask_u8, idx, n_lists, std_floor):
     _lib.check(lib.hypmi_gather_stats(engine._ptr(X), n, nc, X.stride(0),
                                       engine._ptr(mask_u8) if mask_u8 is not None else None,
                                       mask_u8.stride(0) if mask_u8 is not None else 0,
-                                      engine._ptr(idx), idx.stride(0), idx.shape[0], n_lists,
+                                      engine._ptr(idx), idx.shape[1], int(k), n_lists,
                                       float(std_floor), engine._ptr(mean), engine._ptr(istd), ld,
                                       engine.stream_ptr()))
     return mean, istd, ld
@@ -52,8 +60,8 @@ def adapt_s_norm_device(S, A_ec, A_tc, nbest, nbest_discard, mask_ec=None, mask_
         return out[:, :nt]
     t_idx = topk_rows(A_tc, k, int(nbest_discard))  # per test: cohort ranked by coh-vs-test
     e_idx = topk_rows(A_ec, k, int(nbest_discard))  # per enrol: cohort ranked by enr-vs-coh
-    mz, iz, ldz = gather_stats(A_ec, mask_ec, t_idx, nt, std_floor)  # [enrol, test]
-    mt, it, ldt = gather_stats(A_tc, mask_tc, e_idx, ne, std_floor)  # [test, enrol]
+    mz, iz, ldz = gather_stats(A_ec, mask_ec, t_idx, nt, std_floor, k)  # [enrol, test]
+    mt, it, ldt = gather_stats(A_tc, mask_tc, e_idx, ne, std_floor, k)  # [test, enrol]
     _lib.check(lib.hypmi_asnorm_apply(engine._ptr(S), S.stride(0), ne, nt, engine._ptr(mz),
                                       engine._ptr(iz), ldz, engine._ptr(mt), engine._ptr(it), ldt,
                                       engine._ptr(out), ld, engine.stream_ptr()))

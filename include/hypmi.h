@@ -143,21 +143,26 @@ int hypmi_scatter_block(const float* blk, int64_t ldb, const int32_t* ri, int64_
 
 /* ---- score normalisation (hyperion/score_norm) ---------------------------------------------- */
 
-/* Per-row top-k over the cohort: for every row of A[n_rows x nc] the cohort indices ranked
- * discard .. discard+k-1 by descending score, written list-minor: idx_t[j * ldi + row], j < k, in
- * ascending index order.  Replaces np.argsort + flip + slice (adapt_s_norm.py:42-44, 65-67); ties at
- * a boundary are resolved towards the lower cohort index (numpy leaves that order unspecified).
+/* Per-row top-k over the cohort: for every row of A[n_rows x nc] (nc <= 65536) the cohort indices
+ * ranked discard .. discard+k-1 by descending score, in ascending index order.  Replaces
+ * np.argsort + flip + slice (adapt_s_norm.py:42-44, 65-67); ties at a boundary are resolved towards
+ * the lower cohort index (numpy leaves that order unspecified).
+ * List layout (uint16, groups of eight so that one 16-byte load fetches eight entries of a list):
+ *   entry j of the list of row q is idx[((j >> 3) * ldi + q) * 8 + (j & 7)],  ldi >= n_rows,
+ * hypmi_topk_list_bytes(k, ldi) bytes in all, 16-byte aligned.
  * Cohorts up to ~40k entries are selected inside LDS; larger ones need the workspace. */
 int64_t hypmi_topk_workspace_bytes(int64_t n_rows, int nc);
+int64_t hypmi_topk_list_bytes(int k, int64_t ldi);
 int hypmi_topk_rows(const float* A, int64_t n_rows, int nc, int64_t lda, int k, int discard,
-                    int32_t* idx_t, int64_t ldi, void* workspace, int64_t workspace_bytes, void* stream);
+                    uint16_t* idx, int64_t ldi, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Cohort statistics over selected members (adapt_s_norm.py:46-63 and 69-86): for every row r of
- * X[n_rows x nc] and list q: mean[r,q] and istd[r,q] = 1 / max(std, std_floor) of X[r, idx_t[:, q]]
- * (population std).  With mask (uint8 [n_rows x nc], 0 = masked, X already zeroed there) the moments
- * are divided by the unmasked fraction as adapt_s_norm.py:54-60 does. */
+ * X[n_rows x nc] and list q (layout above): mean[r,q] and istd[r,q] = 1 / max(std, std_floor) of
+ * X[r, list_q] (population std).  With mask (uint8 [n_rows x nc], 0 = masked, X already zeroed
+ * there) the moments are divided by the unmasked fraction as adapt_s_norm.py:54-60 does.
+ * The cohort row must fit in LDS (nc <= 40960 without mask). */
 int hypmi_gather_stats(const float* X, int64_t n_rows, int nc, int64_t ldx, const unsigned char* mask,
-                       int64_t ldm, const int32_t* idx_t, int64_t ldi, int k, int64_t n_lists,
+                       int64_t ldm, const uint16_t* idx, int64_t ldi, int k, int64_t n_lists,
                        float std_floor, float* mean, float* istd, int64_t ldo, void* stream);
 
 /* out[e,t] = ((S - mz[e,t]) iz[e,t] + (S - mt[t,e]) it[t,e]) / sqrt(2)  (adapt_s_norm.py:63,86,88). */

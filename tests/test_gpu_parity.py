@@ -219,13 +219,13 @@ def test_topk_ties_and_duplicates():
     every unselected one; ties at the boundary go to the lower index."""
     import torch
 
-    from hyperion_amd.score_norm.adapt_s_norm import topk_rows
+    from hyperion_amd.score_norm.adapt_s_norm import lists_to_numpy, topk_rows
 
     rng = np.random.RandomState(3)
     A = rng.randint(0, 6, size=(37, 500)).astype(np.float32)  # heavy ties
     A[5] = 1.0
     for k, disc in [(50, 0), (17, 9), (500, 0), (1, 499)]:
-        idx = topk_rows(torch.from_numpy(A).cuda(), k, disc).cpu().numpy()[:, :37].T  # [rows, k]
+        idx = lists_to_numpy(topk_rows(torch.from_numpy(A).cuda(), k, disc), k)  # [rows, k]
         for r in range(A.shape[0]):
             order = np.lexsort((np.arange(500), -A[r]))  # descending value, ascending index
             want = np.sort(order[disc:disc + k])
@@ -300,3 +300,38 @@ def test_voxceleb_size_full_matrix():
     assert O.compute_min_dcf(tar_g, non_g, 0.05)[0] == O.compute_min_dcf(tar_r, non_r, 0.05)[0]
     # size-independent property: the matrix of a set against itself is symmetric up to rounding
     assert np.max(np.abs(s - s.T)) <= 2e-4
+
+
+def test_backend_snorm_pipeline_chunked_and_sharded():
+    """Device-resident chain -> SPLDA -> AS-norm pipeline against the oracle, with the test set
+    cut into several chunks and into two shards (the multi-GPU partition, run back to back)."""
+    import synth
+    from hyperion_amd.backend import PLDABackend, shard_range
+    from hyperion_amd.pdfs.plda import SPLDA
+    from hyperion_amd.transforms import LDA, CentWhiten, LNorm, TransformList
+
+    chain = synth.chain_cfg2(d=96, lda_dim=40, seed=3)
+    m = synth.make_splda(40, 12)
+    xe, _ = synth.raw_xvectors(50, d=96, seed=21, num_centers=30)
+    xt, _ = synth.raw_xvectors(333, d=96, seed=22, num_centers=30)
+    xc, _ = synth.raw_xvectors(400, d=96, seed=23, num_centers=200)
+    tl = TransformList([CentWhiten(mu=chain[0][1], T=chain[0][2], name="cw"), LNorm(name="ln"),
+                        LDA(mu=chain[2][1], T=chain[2][2], name="lda")])
+    be = PLDABackend(SPLDA(mu=m["mu"], V=m["V"], W=m["W"]), tl, nbest=50, nbest_discard=2, test_chunk=100)
+    ye, yt, yc = (O.chain_predict(a, chain) for a in (xe, xt, xc))
+    ref = O.adapt_s_norm(O.llr_1vs1(m, ye, yt), O.llr_1vs1(m, yc, yt), O.llr_1vs1(m, ye, yc), 50, 2)
+    coh = be.prepare_cohort(xe, xc)
+    got = be.score_snorm(xt, coh).cpu().numpy().astype(float)
+    err = np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)
+    assert err.max() <= 1e-4, err.max()
+    # two test shards, as two ranks would own them
+    parts = []
+    for r in range(2):
+        lo, hi = shard_range(len(xt), r, 2)
+        parts.append(be.score_snorm(xt[lo:hi], coh).cpu().numpy())
+    assert np.array_equal(np.hstack(parts), got.astype(np.float32))
+    # streaming reduction instead of a materialised matrix
+    acc = []
+    be.score_snorm(xt, coh, reduce=lambda c0, blk: acc.append((c0, float(blk.sum(dtype=__import__("torch").float64)))))
+    assert [c for c, _ in acc] == [0, 100, 200, 300]
+    assert abs(sum(v for _, v in acc) - got.sum()) <= 1e-3 * abs(got).sum()
