@@ -27,10 +27,12 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (256 CU x 256 flo
 HBM_PEAK_GBS = 8000.0
 
 WORKLOADS = {
-    # name: (n_enrol, n_test per GPU, d_in, lda_dim, K)
+    # n_enrol, n_test per GPU, input dim, LDA dim, y_dim; asnorm: cohort size and nbest
     "chain_splda_100k": dict(n_enrol=100_000, n_test=100_000, d=512, lda=200, K=150),
     "chain_splda_20k": dict(n_enrol=20_000, n_test=20_000, d=512, lda=200, K=150),
     "splda_vox1": dict(n_enrol=4874, n_test=4874, d=512, lda=None, K=150),
+    "asnorm_10k_1m": dict(n_enrol=10_000, n_test=1_000_000, d=512, lda=200, K=150, n_coh=20_000, nbest=300),
+    "asnorm_10k_128k": dict(n_enrol=10_000, n_test=131_072, d=512, lda=200, K=150, n_coh=20_000, nbest=300),
 }
 
 
@@ -44,6 +46,8 @@ def parse():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=20000,
                     help="rows/cols of the square slice the CPU baseline is timed on")
+    ap.add_argument("--no-asnorm-stage", action="store_true",
+                    help="skip the extra AS-norm stage measurement of the default workload")
     return ap.parse_args()
 
 
@@ -96,6 +100,55 @@ def cpu_baseline(cfg, chain, model, sample):
                       % (n, n, n, dt)}
 
 
+def asnorm_stage(plda, preproc, cfg, n_test, steps, warmup, rank, world=1):
+    """Chain + SPLDA + adaptive S-norm (20k cohort, top-300) for n_test test vectors against 10k
+    enrolment models, everything device resident; returns normalised scores/s of one GPU."""
+    import torch
+
+    from hyperion_amd import engine
+    from hyperion_amd.backend import PLDABackend
+
+    ne, nc, nbest = 10_000, cfg.get("n_coh", 20_000), cfg.get("nbest", 300)
+    be = PLDABackend(plda, preproc, nbest=nbest, test_chunk=65536)
+    xe = engine.upload(make_inputs(cfg, ne, 41))
+    xc = engine.upload(make_inputs(cfg, nc, 42))
+    xt = engine.upload(make_inputs(cfg, n_test, 43 + 1000 * rank))
+    out = torch.empty((ne, engine.round_up(n_test, 32)), dtype=torch.float32, device="cuda")[:, :n_test]
+
+    def step():
+        coh = be.prepare_cohort(xe, xc, rank=rank, world=world)  # one all-gather of top-k lists
+        be.score_snorm(xt, coh, out=out)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"workload": "chain+SPLDA+AdaptSNorm: %d enrol x %d test, cohort %d, nbest %d, one GPU"
+                        % (ne, n_test, nc, nbest),
+            "value": ne * n_test / dt, "unit": "normalised scores/s", "ms_per_step": dt * 1e3,
+            "gather_GBs": 2.0 * nbest * 4 * ne * n_test / dt / 1e9,
+            "checksum": float(out.sum(dtype=torch.float64).item())}, be, (xe, xc, xt, out)
+
+
+def asnorm_check(be, bufs, chain, model, cfg):
+    """Spot check of the AS-norm output against the oracle on a slab (all 20k cohort, 8 enrol rows,
+    64 tests): the slab's rows/columns are recomputed on the CPU from the same raw inputs."""
+    from oracle import plda_ref as O
+
+    xe, xc, xt, out = bufs
+    r, c = 8, 64
+    f = lambda t, n: O.chain_predict(t[:n].cpu().numpy().astype(np.float64), chain)  # noqa: E731
+    ye, yt, yc = f(xe, r), f(xt, c), f(xc, xc.shape[0])
+    ref = O.adapt_s_norm(O.llr_1vs1(model, ye, yt), O.llr_1vs1(model, yc, yt), O.llr_1vs1(model, ye, yc),
+                         cfg.get("nbest", 300), 0)
+    got = out[:r, :c].cpu().numpy().astype(np.float64)
+    return float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)))
+
+
 def main():
     args = parse()
     import torch
@@ -125,6 +178,9 @@ def main():
         preproc = TransformList([CentWhiten(mu=chain[0][1], T=chain[0][2], name="cw"), LNorm(name="ln"),
                                  LDA(mu=chain[2][1], T=chain[2][2], name="lda")])
     plan = plda.score_plan(preproc)
+
+    if "n_coh" in cfg:
+        return main_asnorm(args, cfg, chain, model, plda, preproc, plan, world, rank, dist)
 
     n1, n2 = cfg["n_enrol"], cfg["n_test"]
     x1_h = make_inputs(cfg, n1, 21)
@@ -222,8 +278,48 @@ def main():
         err = np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)
         out["parity"] = {"max_err_over_max_abs_1": float(err.max()), "slab": [r, c],
                          "checksum": float(S.sum(dtype=torch.float64).item())}
+    if rank == 0 and world == 1 and not args.no_asnorm_stage and chain is not None:
+        del S
+        torch.cuda.empty_cache()
+        st, be, bufs = asnorm_stage(plda, preproc, cfg, 131_072, 2, 1, rank)
+        if not args.no_check:
+            st["parity_max_err_over_max_abs_1"] = asnorm_check(be, bufs, chain, model, cfg)
+        out["asnorm_stage"] = st
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, chain, model, args.cpu_sample)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main_asnorm(args, cfg, chain, model, plda, preproc, plan, world, rank, dist):
+    """AS-norm workloads: value = normalised scores/s over all ranks (test rows sharded)."""
+    import torch
+
+    if world > 1:
+        dist.barrier()
+    st, be, bufs = asnorm_stage(plda, preproc, cfg, cfg["n_test"], args.steps, args.warmup, rank, world)
+    dt = st["ms_per_step"] * 1e-3
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ne, nt = 10_000, cfg["n_test"]
+    out = {
+        "metric": "PLDA trial scores/sec (512-d, SPLDA+AS-norm)", "value": ne * nt * world / dt,
+        "unit": "scores/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": args.workload + ": " + st["workload"], "parallelism":
+                   "test rows sharded over %d GPU(s), enrol and cohort replicated" % world},
+        "roofline": {"kernel": "gather_stats_kernel<2,false>", "bound": "hbm",
+                     "note": "bound by random LDS gathers, not HBM; achieved = gathered bytes / step time",
+                     "achieved": st["gather_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": st["gather_GBs"] / HBM_PEAK_GBS, "traffic": None},
+    }
+    if rank == 0 and not args.no_check and chain is not None:
+        out["parity"] = {"max_err_over_max_abs_1": asnorm_check(be, bufs, chain, model, cfg)}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -11,12 +11,37 @@
 //     piece of G2, copied by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction) into one
 //     of two buffers while the previous tile is being multiplied;
 //   * per tile a wave issues KP/8 ds_read_b128 and KP*RT/2 MFMAs and stores a (32*RT) x 32 block
-//     of S; every store instruction writes two full 128-byte lines.
+//     of S through one buffer descriptor (scalar row offset + one 32-bit lane offset, so a store
+//     costs one SALU instruction and the store); every store writes two full 128-byte lines.
+// Measured at 100k x 100k, KP = 152 (MI355X): 22.2 ms = 135 TFLOP/s; the same loop without the
+// stores runs 20.8 ms, with 64-bit per-lane store addresses 24.0 ms; raising s_setprio per
+// workgroup or per tile half, four waves per SIMD (RT = 1) and 16-byte stores were all within 1.5 %.
 // The k order inside one 16-byte read is shared by both operands (lane half h owns k = 8s+4h+e),
 // which is all an inner product needs.
 #include "common.h"
 
-namespace {
+namespace hypmi_detail {
+
+// Stores a (32*RT) x 32 accumulator block through one buffer descriptor: the row offsets are scalar
+// (soffset), the lane part is one 32-bit voffset, so a store costs one SALU instruction and the store.
+// The buffer builtins exist only in the device pass of the compiler.
+template <int RT>
+__device__ __forceinline__ void store_tile_buffer(const f32x16 (&acc)[RT], float* tile_base, unsigned ldo,
+                                                  unsigned voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned span = (unsigned)(32 * RT) * ldo * 4u;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile_base, 0, span, 0x00020000);
+    const int vb = (int)(voff * 4u);
+    const int row_bytes = (int)ldo * 4;
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int rr = 32 * t + (e & 3) + 8 * (e >> 2);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][e]), rsrc, vb, rr * row_bytes, 2);
+        }
+#endif
+}
 
 template <int KP, int RT>
 __global__ __launch_bounds__(256, 2) void score_rs_kernel(const float* __restrict__ G1,
@@ -27,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void score_rs_kernel(const float* __restric
     static_assert(KP % 8 == 0, "packed width must be a multiple of 8");
     constexpr int KS = KP / 8;        // 16-byte steps per row = LDS-DMA instructions per tile
     constexpr int TILE_F4 = 8 * KP;   // float4 per 32-row tile
-    extern __shared__ __attribute__((aligned(16))) float4 tile[];  // [2][TILE_F4]
+    __shared__ __attribute__((aligned(16))) float4 tile[2 * TILE_F4];  // two tile buffers
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -130,13 +155,7 @@ __global__ __launch_bounds__(256, 2) void score_rs_kernel(const float* __restric
         const int64_t rows_left = n1 - i0;  // wave-uniform
         if (col0 + r < n2) {
             if (rows_left >= 32 * RT) {
-#pragma unroll
-                for (int t = 0; t < RT; ++t)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        float* base = S + (i0 + 32 * t + (e & 3) + 8 * (e >> 2)) * ldo_t + col0;
-                        __builtin_nontemporal_store(acc[t][e], base + voff);
-                    }
+                store_tile_buffer<RT>(acc, S + i0 * ldo_t + col0, (unsigned)ldo_t, voff);
             } else {
 #pragma unroll
                 for (int t = 0; t < RT; ++t)
@@ -151,14 +170,16 @@ __global__ __launch_bounds__(256, 2) void score_rs_kernel(const float* __restric
     }
 }
 
-template <int KP, int RT>
-int launch_rs(const float* G1, int64_t n1, const float* G2, int64_t n2, float* S, int64_t lds,
-              hipStream_t stream) {
-    const int64_t rows_per_wg = 128 * RT;
+struct LaunchGeom {
+    int64_t gx, gy;
+    int tiles_per_chunk;
+};
+
+// enough workgroups to fill 256 CUs several times over, but long enough streams that loading the
+// stationary rows (one pass over rows_per_wg * KP floats) stays a small fraction
+static int launch_geometry(int64_t n1, int64_t n2, int rows_per_wg, LaunchGeom* g) {
     const int64_t gx = (n1 + rows_per_wg - 1) / rows_per_wg;
     const int64_t ntiles = (n2 + 31) / 32;
-    // enough workgroups to fill 256 CUs several times over, but long enough streams that loading
-    // the stationary rows (one pass over rows_per_wg * KP floats) stays a small fraction
     int64_t tiles_per_chunk = 64;
     while (tiles_per_chunk > 8 && gx * ((ntiles + tiles_per_chunk - 1) / tiles_per_chunk) < 2048)
         tiles_per_chunk /= 2;
@@ -168,18 +189,40 @@ int launch_rs(const float* G1, int64_t n1, const float* G2, int64_t n2, float* S
         gy = (ntiles + tiles_per_chunk - 1) / tiles_per_chunk;
     }
     HYPMI_REQUIRE(gx <= 0x7fffffffLL, "score: too many enrol rows");
-    const size_t shmem = 2 * 32 * KP * sizeof(float);
-    if (shmem > 48 * 1024) {
-        HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_rs_kernel<KP, RT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    }
-    hipLaunchKernelGGL((score_rs_kernel<KP, RT>), dim3((unsigned)gx, (unsigned)gy), dim3(256), shmem,
-                       stream, G1, G2, S, n1, n2, lds, (int)tiles_per_chunk);
-    HYPMI_HIP(hipGetLastError());
+    g->gx = gx;
+    g->gy = gy;
+    g->tiles_per_chunk = (int)tiles_per_chunk;
     return HYPMI_OK;
 }
 
-}  // namespace
+// One plain launcher per instantiation.  The tile buffers are static LDS (up to 76 KiB at KP = 304),
+// so no per-kernel attribute call is needed before the launch.
+#define HYPMI_DEFINE_LAUNCH(KP, RT)                                                               \
+    static int launch_##KP(const float* G1, int64_t n1, const float* G2, int64_t n2, float* S,          \
+                           int64_t lds, hipStream_t stream) {                                          \
+        LaunchGeom g;                                                                                  \
+        int rc = launch_geometry(n1, n2, 128 * RT, &g);                                                \
+        if (rc != HYPMI_OK) return rc;                                                                 \
+        hipLaunchKernelGGL((score_rs_kernel<KP, RT>), dim3((unsigned)g.gx, (unsigned)g.gy),            \
+                           dim3(256), 0, stream, G1, G2, S, n1, n2, lds, g.tiles_per_chunk);           \
+        HYPMI_HIP(hipGetLastError());                                                                  \
+        return HYPMI_OK;                                                                               \
+    }
+
+HYPMI_DEFINE_LAUNCH(16, 2)
+HYPMI_DEFINE_LAUNCH(32, 2)
+HYPMI_DEFINE_LAUNCH(64, 2)
+HYPMI_DEFINE_LAUNCH(96, 2)
+HYPMI_DEFINE_LAUNCH(128, 2)
+HYPMI_DEFINE_LAUNCH(152, 2)
+HYPMI_DEFINE_LAUNCH(192, 1)
+HYPMI_DEFINE_LAUNCH(232, 1)
+HYPMI_DEFINE_LAUNCH(304, 1)
+#undef HYPMI_DEFINE_LAUNCH
+
+}  // namespace hypmi_detail
+
+using namespace hypmi_detail;
 
 // Packed widths with a register-stationary instantiation; wider models use the K-loop GEMM.
 int hypmi_kp_for_k(int K) {
@@ -203,15 +246,15 @@ extern "C" int hypmi_score(const float* G1, int64_t n1, const float* G2, int64_t
     HYPMI_REQUIRE(aligned16(G1) && aligned16(G2), "score: packed rows must be 16-byte aligned");
     if (n1 == 0 || n2 == 0) return HYPMI_OK;
     switch (kp) {
-        case 16: return launch_rs<16, 2>(G1, n1, G2, n2, S, lds, stream);
-        case 32: return launch_rs<32, 2>(G1, n1, G2, n2, S, lds, stream);
-        case 64: return launch_rs<64, 2>(G1, n1, G2, n2, S, lds, stream);
-        case 96: return launch_rs<96, 2>(G1, n1, G2, n2, S, lds, stream);
-        case 128: return launch_rs<128, 2>(G1, n1, G2, n2, S, lds, stream);
-        case 152: return launch_rs<152, 2>(G1, n1, G2, n2, S, lds, stream);
-        case 192: return launch_rs<192, 1>(G1, n1, G2, n2, S, lds, stream);
-        case 232: return launch_rs<232, 1>(G1, n1, G2, n2, S, lds, stream);
-        case 304: return launch_rs<304, 1>(G1, n1, G2, n2, S, lds, stream);
+        case 16: return launch_16(G1, n1, G2, n2, S, lds, stream);
+        case 32: return launch_32(G1, n1, G2, n2, S, lds, stream);
+        case 64: return launch_64(G1, n1, G2, n2, S, lds, stream);
+        case 96: return launch_96(G1, n1, G2, n2, S, lds, stream);
+        case 128: return launch_128(G1, n1, G2, n2, S, lds, stream);
+        case 152: return launch_152(G1, n1, G2, n2, S, lds, stream);
+        case 192: return launch_192(G1, n1, G2, n2, S, lds, stream);
+        case 232: return launch_232(G1, n1, G2, n2, S, lds, stream);
+        case 304: return launch_304(G1, n1, G2, n2, S, lds, stream);
         default:
             return hypmi_launch_gemm_nt(G1, kp, G2, kp, nullptr, S, lds, n1, n2, kp, stream);
     }
