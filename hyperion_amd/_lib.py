@@ -60,6 +60,12 @@ SIGNATURES = {
     "hypmi_affine": (ctypes.c_int, [c_void_p, i64, i64, ctypes.c_int, c_void_p, i64, c_void_p,
                                     ctypes.c_int, c_void_p, i64, c_void_p]),
     "hypmi_lnorm_rows": (ctypes.c_int, [c_void_p, i64, i64, ctypes.c_int, c_void_p]),
+    "hypmi_prologue_f64_workspace_bytes": (i64, [c_void_p, i64]),
+    "hypmi_prologue_f64": (ctypes.c_int, [c_void_p, c_void_p, i64, i64, ctypes.c_int, c_void_p, i64,
+                                          c_void_p, c_void_p, i64, c_void_p]),
+    "hypmi_refine_scores": (ctypes.c_int, [c_void_p, i64, i64, i64, c_void_p, c_void_p, i64,
+                                           ctypes.c_int, c_void_p, c_void_p, ctypes.c_float,
+                                           ctypes.c_float, c_void_p, c_void_p]),
     "hypmi_pool_rows": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, c_void_p, c_void_p, i64,
                                        ctypes.c_int, c_void_p, i64, c_void_p, c_void_p]),
     "hypmi_packed_width": (ctypes.c_int, [ctypes.c_int]),

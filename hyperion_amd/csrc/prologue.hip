@@ -25,52 +25,47 @@ extern "C" const char* hypmi_last_error(void) { return g_err; }
 extern "C" int hypmi_version(void) { return 1; }
 
 // ------------------------------------------------------------------------------------ plan
-struct Segment {
-    float* Wt = nullptr;   // [d_out x ldw] transposed weight, zero padded (nullptr = identity)
-    float* bias = nullptr; // [d_out] or nullptr
-    int64_t ldw = 0;
-    int d_in = 0, d_out = 0;
-    bool lnorm = false;
-};
-
-struct hypmi_plan {
-    int d_in = 0, n_seg = 0, d_last = 0, K = 0, KP = 0;
-    Segment seg[HYPMI_MAX_SEG];
-    Segment fin;  // [At | An]^T, 2K outputs
-    double c = 0.0;
-    int max_dim = 0;
-};
+#include "plan.h"
 
 namespace {
 
-int upload_transposed(const double* A, int d_in, int d_out, float** out, int64_t* ldw) {
-    // A is [d_in x d_out] row-major on the host; device copy is [d_out x ld] fp32, ld = d_in up to 4
-    const int64_t ld = round_up(d_in, 4);
-    std::vector<float> tmp((size_t)d_out * ld, 0.f);
-    for (int i = 0; i < d_in; ++i)
-        for (int j = 0; j < d_out; ++j) tmp[(size_t)j * ld + i] = (float)A[(size_t)i * d_out + j];
-    float* dev = nullptr;
-    if (hipMalloc(&dev, tmp.size() * sizeof(float)) != hipSuccess) {
-        hypmi_set_error("plan: device allocation of %zu bytes failed", tmp.size() * sizeof(float));
+template <typename T>
+int to_device(const std::vector<T>& host, T** out) {
+    T* dev = nullptr;
+    if (hipMalloc(&dev, host.size() * sizeof(T)) != hipSuccess) {
+        hypmi_set_error("plan: device allocation of %zu bytes failed", host.size() * sizeof(T));
         return HYPMI_ENOMEM;
     }
-    HYPMI_HIP(hipMemcpy(dev, tmp.data(), tmp.size() * sizeof(float), hipMemcpyHostToDevice));
+    HYPMI_HIP(hipMemcpy(dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
     *out = dev;
-    *ldw = ld;
     return HYPMI_OK;
 }
 
-int upload_vec(const double* b, int n, float** out) {
-    std::vector<float> tmp(n);
-    for (int i = 0; i < n; ++i) tmp[i] = (float)b[i];
-    float* dev = nullptr;
-    if (hipMalloc(&dev, n * sizeof(float)) != hipSuccess) {
-        hypmi_set_error("plan: device allocation failed");
-        return HYPMI_ENOMEM;
-    }
-    HYPMI_HIP(hipMemcpy(dev, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice));
-    *out = dev;
-    return HYPMI_OK;
+// A is [d_in x d_out] row-major on the host; the device copies are transposed, [d_out x ld] with
+// ld = d_in rounded up to 4 and zero padding, once in fp32 (matrix-core path) and once in fp64
+// (refinement path).
+int upload_transposed(const double* A, int d_in, int d_out, Segment* seg) {
+    const int64_t ld = round_up(d_in, 4);
+    std::vector<float> t32((size_t)d_out * ld, 0.f);
+    std::vector<double> t64((size_t)d_out * ld, 0.0);
+    for (int i = 0; i < d_in; ++i)
+        for (int j = 0; j < d_out; ++j) {
+            t64[(size_t)j * ld + i] = A[(size_t)i * d_out + j];
+            t32[(size_t)j * ld + i] = (float)A[(size_t)i * d_out + j];
+        }
+    seg->ldw = ld;
+    int rc = to_device(t32, &seg->Wt);
+    if (rc == HYPMI_OK) rc = to_device(t64, &seg->Wt64);
+    return rc;
+}
+
+int upload_vec(const double* b, int n, Segment* seg) {
+    std::vector<float> t32(n);
+    std::vector<double> t64(b, b + n);
+    for (int i = 0; i < n; ++i) t32[i] = (float)b[i];
+    int rc = to_device(t32, &seg->bias);
+    if (rc == HYPMI_OK) rc = to_device(t64, &seg->bias64);
+    return rc;
 }
 
 }  // namespace
@@ -78,11 +73,9 @@ int upload_vec(const double* b, int n, float** out) {
 extern "C" void hypmi_plan_destroy(hypmi_plan* p) {
     if (!p) return;
     for (int i = 0; i < HYPMI_MAX_SEG; ++i) {
-        if (p->seg[i].Wt) (void)hipFree(p->seg[i].Wt);
-        if (p->seg[i].bias) (void)hipFree(p->seg[i].bias);
+        p->seg[i].release();
     }
-    if (p->fin.Wt) (void)hipFree(p->fin.Wt);
-    if (p->fin.bias) (void)hipFree(p->fin.bias);
+    p->fin.release();
     delete p;
 }
 
@@ -112,14 +105,14 @@ extern "C" int hypmi_plan_create(const hypmi_plan_desc* d, hypmi_plan** out) {
             break;
         }
         if (s.A) {
-            rc = upload_transposed(s.A, cur, s.d_out, &t.Wt, &t.ldw);
-            if (rc == HYPMI_OK && s.b) rc = upload_vec(s.b, s.d_out, &t.bias);
+            rc = upload_transposed(s.A, cur, s.d_out, &t);
+            if (rc == HYPMI_OK && s.b) rc = upload_vec(s.b, s.d_out, &t);
         } else if (s.b) {
             // bias without a matrix: identity weight keeps one code path
             std::vector<double> I((size_t)cur * cur, 0.0);
             for (int k = 0; k < cur; ++k) I[(size_t)k * cur + k] = 1.0;
-            rc = upload_transposed(I.data(), cur, cur, &t.Wt, &t.ldw);
-            if (rc == HYPMI_OK) rc = upload_vec(s.b, s.d_out, &t.bias);
+            rc = upload_transposed(I.data(), cur, cur, &t);
+            if (rc == HYPMI_OK) rc = upload_vec(s.b, s.d_out, &t);
         }
         cur = s.d_out;
         if (cur > p->max_dim) p->max_dim = cur;
@@ -139,8 +132,8 @@ extern "C" int hypmi_plan_create(const hypmi_plan_desc* d, hypmi_plan** out) {
         }
         p->fin.d_in = cur;
         p->fin.d_out = 2 * K;
-        rc = upload_transposed(W.data(), cur, 2 * K, &p->fin.Wt, &p->fin.ldw);
-        if (rc == HYPMI_OK) rc = upload_vec(b.data(), 2 * K, &p->fin.bias);
+        rc = upload_transposed(W.data(), cur, 2 * K, &p->fin);
+        if (rc == HYPMI_OK) rc = upload_vec(b.data(), 2 * K, &p->fin);
         p->KP = hypmi_kp_for_k(K);
     }
     if (rc != HYPMI_OK) {

@@ -66,6 +66,21 @@ def upload(x, dtype=None):
     return buf[:, :d]
 
 
+def upload64(x):
+    """numpy / device array -> contiguous device float64 [n, d] (input of the refinement path)."""
+    torch = require_gpu()
+    if isinstance(x, torch.Tensor):
+        return x.to(device="cuda", dtype=torch.float64).contiguous()
+    x = np.asarray(x)
+    if x.ndim != 2:
+        raise ValueError("expected a 2-D array of embeddings, got shape %s" % (x.shape,))
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).cuda()
+
+
+# fp32 error model of one score: |err| <= ERR_COEFF * (|g1| |g2| + |q1| + |q2|), 8 units of 2^-24
+ERR_COEFF = 8.0 * 2.0 ** -24
+
+
 def _as_c(a):
     """float64 C-contiguous copy + ctypes pointer (None stays NULL)."""
     if a is None:
@@ -165,6 +180,21 @@ class Plan:
                                             _ptr(ws), nbytes, stream_ptr()))
         return G
 
+    def prologue_f64(self, x64, side):
+        """x64: device float64 [n, d_in] -> (G64 [n, K + 2] rows [g, q(+c), |g|], bnd [n, 2] floats)."""
+        torch = _torch()
+        self._check_x(x64)
+        n = x64.shape[0]
+        G = torch.empty((n, self.k + 2), dtype=torch.float64, device=x64.device)
+        bnd = torch.empty((n, 2), dtype=torch.float32, device=x64.device)
+        if n:
+            nbytes = self._lib.hypmi_prologue_f64_workspace_bytes(self._h, n)
+            ws = torch.empty(max(nbytes // 8, 2), dtype=torch.float64, device=x64.device)
+            _lib.check(self._lib.hypmi_prologue_f64(self._h, _ptr(x64), n, x64.stride(0), int(side),
+                                                    _ptr(G), G.stride(0), _ptr(bnd), _ptr(ws), nbytes,
+                                                    stream_ptr()))
+        return G, bnd
+
     def transform(self, x):
         """x: device fp32 [n, d_in] -> device fp32 [n, d_out] (pre-processing chain only)."""
         torch = _torch()
@@ -197,6 +227,22 @@ def score(G1, G2, out=None):
         _lib.check(lib.hypmi_score(_ptr(G1), n1, _ptr(G2), n2, kp, _ptr(out), out.stride(0),
                                    stream_ptr()))
     return out
+
+
+def refine_scores(S, G1_64, bnd1, G2_64, bnd2, rel_tol=1e-4, err_coeff=ERR_COEFF, count=False):
+    """Replace in place the entries of S whose fp32 error bound is not below rel_tol * |s| by their
+    float64 value.  Returns the number of refined entries when count is set."""
+    torch = _torch()
+    lib = _lib.load()
+    n1, n2 = S.shape
+    K = G1_64.shape[1] - 2
+    counter = torch.zeros(1, dtype=torch.int64, device=S.device) if count else None
+    if n1 and n2:
+        _lib.check(lib.hypmi_refine_scores(_ptr(S), S.stride(0), n1, n2, _ptr(G1_64), _ptr(G2_64),
+                                           G1_64.stride(0), K, _ptr(bnd1), _ptr(bnd2), float(rel_tol),
+                                           float(err_coeff), _ptr(counter) if count else None,
+                                           stream_ptr()))
+    return int(counter.item()) if count else None
 
 
 def to_host(t, dtype):

@@ -107,15 +107,26 @@ class PLDABase(HypModel):
         return plan
 
     # ---- 1 vs 1 -----------------------------------------------------------------------------
-    def llr_1vs1(self, x1, x2, preproc=None):
+    def llr_1vs1(self, x1, x2, preproc=None, refine=None):
         """Log-likelihood ratio of every (x1[i], x2[j]) pair: [N1, N2] `float_cpu()` array.
-        numpy in / numpy out; device tensors in give a device tensor out."""
+        numpy in / numpy out; device tensors in give a device tensor out.
+
+        refine: scores whose fp32 error bound is not below half of 1e-4 |s| (scores that cancel to
+        about zero, ~1 % of a calibrated back-end's trials) are re-evaluated in float64 on the
+        device, so that every score matches the float64 reference to 1e-4 relative.  Default: on for
+        numpy inputs, off for device tensors."""
         torch = engine.require_gpu()
         plan = self.score_plan(preproc)
         dev_out = isinstance(x1, torch.Tensor) and isinstance(x2, torch.Tensor)
+        if refine is None:
+            refine = not dev_out
         G1 = plan.prologue(engine.upload(x1), SIDE_ENROL)
         G2 = plan.prologue(engine.upload(x2), SIDE_TEST)
         S = engine.score(G1, G2)
+        if refine and S.numel():
+            D1, b1 = plan.prologue_f64(engine.upload64(x1), SIDE_ENROL)
+            D2, b2 = plan.prologue_f64(engine.upload64(x2), SIDE_TEST)
+            engine.refine_scores(S, D1, b1, D2, b2, rel_tol=0.5e-4)
         return S if dev_out else engine.to_host(S, float_cpu())
 
     # ---- sufficient statistics ----------------------------------------------------------------

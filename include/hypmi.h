@@ -115,6 +115,25 @@ int hypmi_affine(const float* x, int64_t n, int64_t ldx, int d_in, const float* 
 /* In-place length normalisation of rows: y <- sqrt(d) y / (|y| + 1e-10)  (lnorm.py:16-17). */
 int hypmi_lnorm_rows(float* y, int64_t n, int64_t ldy, int d, void* stream);
 
+/* ---- double-precision refinement ------------------------------------------------------------ */
+
+/* fp64 embedding prologue (same plan, fp64 weights, f64 matrix cores): the float64 arithmetic of
+ * hyperion/pdfs/plda/splda.py:297-310 without the fp32 rounding of the fast path.
+ * x: [n x d_in] fp64.  G64: [n x ldg] rows [g(0..K-1), q (+ c on the test side), |g|], ldg >= K + 2.
+ * bnd: [n x 2] floats (|g|, |q|) used for error bounds. */
+int64_t hypmi_prologue_f64_workspace_bytes(const hypmi_plan* plan, int64_t n);
+int hypmi_prologue_f64(const hypmi_plan* plan, const double* x, int64_t n, int64_t ldx, int side,
+                       double* G64, int64_t ldg, float* bnd, void* workspace, int64_t workspace_bytes,
+                       void* stream);
+
+/* Replace by their fp64 value the scores whose fp32 error bound is not below rel_tol * |s|:
+ *   err_coeff * (|g1_i| |g2_j| + |q1_i| + |q2_j|) > rel_tol * |S[i,j]|
+ * (scores that cancel to ~0; with err_coeff = 8 * 2^-24 about 1-2 % of a calibrated back-end's
+ * non-target scores).  counter (optional, device) accumulates the number of refined entries. */
+int hypmi_refine_scores(float* S, int64_t lds, int64_t n1, int64_t n2, const double* G1_64,
+                        const double* G2_64, int64_t ldg, int K, const float* bnd1, const float* bnd2,
+                        float rel_tol, float err_coeff, unsigned long long* counter, void* stream);
+
 /* ---- multi-session enrolment (hyperion/pdfs/plda/plda_base.py:249-351) ---------------------- */
 
 /* Class pooling: out[g,:] = sum (mean != 0: average) of x[order[r],:], r in [offsets[g], offsets[g+1]).

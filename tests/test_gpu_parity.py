@@ -335,3 +335,48 @@ def test_backend_snorm_pipeline_chunked_and_sharded():
     be.score_snorm(xt, coh, reduce=lambda c0, blk: acc.append((c0, float(blk.sum(dtype=__import__("torch").float64)))))
     assert [c for c, _ in acc] == [0, 100, 200, 300]
     assert abs(sum(v for _, v in acc) - got.sum()) <= 1e-3 * abs(got).sum()
+
+
+def test_strict_relative_parity_with_refinement():
+    """With the fp64 refinement pass (default for numpy inputs) every score of the VoxCeleb-size
+    matrix matches the float64 oracle to 1e-4 RELATIVE, including those that cancel to ~0; without
+    it only the mixed bound holds.  Also checks the fraction of refined entries is small."""
+    import torch
+
+    import synth
+    from hyperion_amd import engine
+    from hyperion_amd.engine import SIDE_ENROL, SIDE_TEST
+
+    m, x, cls = synth.voxceleb_like()
+    model = make("splda", m)
+    ref = O.llr_1vs1(m, x, x)
+    s = model.llr_1vs1(x, x)  # numpy in -> refined
+    rel = np.abs(s - ref) / np.abs(ref)
+    assert rel.max() <= 1e-4, rel.max()
+    raw = model.llr_1vs1(x, x, refine=False)
+    rel_raw = np.abs(raw - ref) / np.abs(ref)
+    assert (rel_raw > 1e-4).mean() > 1e-5  # the fp32 path alone does miss the strict bound somewhere
+    assert np.max(np.abs(raw - ref) / np.maximum(np.abs(ref), 1.0)) <= 1e-4
+    # how many entries the refinement touches
+    plan = model.score_plan()
+    xd = engine.upload(x)
+    S = engine.score(plan.prologue(xd, SIDE_ENROL), plan.prologue(xd, SIDE_TEST))
+    D1, b1 = plan.prologue_f64(engine.upload64(x), SIDE_ENROL)
+    D2, b2 = plan.prologue_f64(engine.upload64(x), SIDE_TEST)
+    n = engine.refine_scores(S, D1, b1, D2, b2, rel_tol=0.5e-4, count=True)
+    assert 0 < n < 0.05 * S.numel(), n
+    # the fp64 packed rows themselves: g.g + q1 + q2(+c) reproduces the oracle to 1e-9
+    s64 = (D1[:50, :-2] @ D2[:60, :-2].T + D1[:50, -2:-1] + D2[:60, -2].unsqueeze(0)).cpu().numpy()
+    assert np.max(np.abs(s64 - ref[:50, :60])) <= 1e-9 * np.max(np.abs(ref))
+    assert isinstance(model.llr_1vs1(xd, xd), torch.Tensor)  # device in -> device out, unrefined
+
+
+@pytest.mark.parametrize("kind", ["splda", "frplda", "plda"])
+def test_refinement_golden_strict(golden, kind):
+    """Golden cases under the strict relative bound (numpy path, refinement on), incl. the chain."""
+    g = golden("llr_1vs1")
+    for tag in "ab":
+        m = model_from(g, "%s_%s_" % (kind, tag), kind)
+        s = make(kind, m).llr_1vs1(g["x1_" + tag], g["x2_" + tag])
+        ref = g["%s_%s_scores" % (kind, tag)]
+        assert np.max(np.abs(s - ref) / np.abs(ref)) <= 1e-4
