@@ -26,6 +26,23 @@ class Segment(ctypes.Structure):
     _fields_ = [("A", c_double_p), ("b", c_double_p), ("d_out", i32), ("lnorm", i32)]
 
 
+class TopkExact(ctypes.Structure):
+    _fields_ = [
+        ("mode", i32),
+        ("A64", c_void_p),
+        ("lda64", i64),
+        ("G_rows", c_void_p),
+        ("G_coh", c_void_p),
+        ("ldg", i64),
+        ("K", i32),
+        ("bnd_rows", c_void_p),
+        ("coh_gmax", ctypes.c_float),
+        ("coh_qmax", ctypes.c_float),
+        ("err_coeff", ctypes.c_float),
+        ("counters", c_void_p),
+    ]
+
+
 class PlanDesc(ctypes.Structure):
     _fields_ = [
         ("d_in", i32),
@@ -78,7 +95,7 @@ SIGNATURES = {
     "hypmi_topk_workspace_bytes": (i64, [i64, ctypes.c_int]),
     "hypmi_topk_list_bytes": (i64, [ctypes.c_int, i64]),
     "hypmi_topk_rows": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, i64, ctypes.c_int, ctypes.c_int,
-                                       c_void_p, i64, c_void_p, i64, c_void_p]),
+                                       c_void_p, i64, ctypes.POINTER(TopkExact), c_void_p, i64, c_void_p]),
     "hypmi_gather_stats": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, i64, c_void_p, i64, c_void_p,
                                           i64, ctypes.c_int, i64, ctypes.c_float, c_void_p, c_void_p,
                                           i64, c_void_p]),

@@ -51,12 +51,16 @@ class PLDABackend:
     """plda: a hyperion_amd SPLDA / FRPLDA / PLDA; preproc: optional TransformList folded into the
     embedding prologue; nbest / nbest_discard: adaptive S-norm cohort selection."""
 
-    def __init__(self, plda, preproc=None, nbest=300, nbest_discard=0, test_chunk=65536):
+    def __init__(self, plda, preproc=None, nbest=300, nbest_discard=0, test_chunk=65536, exact_topk=True):
         self.plda = plda
         self.plan = plda.score_plan(preproc)
         self.nbest = int(nbest)
         self.nbest_discard = int(nbest_discard)
         self.test_chunk = int(test_chunk)
+        # re-decide top-k members that fp32 cannot separate from the selection boundary with fp64
+        # scores (costs one fp64 prologue per vector; without it ~0.05 % of test columns pick one
+        # different cohort member than float64 arithmetic would)
+        self.exact_topk = bool(exact_topk)
 
     # ---- embeddings ---------------------------------------------------------------------------
     def embed(self, x, side):
@@ -82,10 +86,17 @@ class PLDABackend:
         k = min(self.nbest, nc - self.nbest_discard)
         counts = [8 * (shard_range(ne, r, world)[1] - shard_range(ne, r, world)[0]) for r in range(world)]
         lo, hi = shard_range(ne, rank, world)
-        local = topk_rows(A_ec[lo:hi], k, self.nbest_discard)[:, :hi - lo]  # [k/8, rows, 8]
+        exact, coh64 = None, None
+        if self.exact_topk:
+            Gc64, bc = self.plan.prologue_f64(engine.upload64(x_cohort), SIDE_TEST)
+            coh64 = {"G_coh": Gc64, "coh_gmax": float(bc[:, 0].max()), "coh_qmax": float(bc[:, 1].max())}
+            xe64 = engine.upload64(x_enrol[lo:hi])
+            Ge64, be = self.plan.prologue_f64(xe64, SIDE_ENROL)
+            exact = dict(coh64, G_rows=Ge64, bnd_rows=be)
+        local = topk_rows(A_ec[lo:hi], k, self.nbest_discard, exact)[:, :hi - lo]  # [k/8, rows, 8]
         e_idx = all_gather_lists(local.reshape(local.shape[0], -1), counts, group)
         e_idx = e_idx.reshape(e_idx.shape[0], -1, 8).contiguous()
-        return {"Ge": Ge, "Gc_test": Gc_test, "A_ec": A_ec, "e_idx": e_idx, "k": k}
+        return {"Ge": Ge, "Gc_test": Gc_test, "A_ec": A_ec, "e_idx": e_idx, "k": k, "coh64": coh64}
 
     def score_snorm(self, x_test, cohort, out=None, reduce=None):
         """AS-normalised scores of every enrolment model against `x_test` (this rank's shard).
@@ -109,7 +120,11 @@ class PLDABackend:
             Gt_rows = self.plan.prologue(xc, SIDE_ENROL)  # tests as rows of the cohort panel
             Gt_cols = self.plan.prologue(xc, SIDE_TEST)   # tests as columns of the trial matrix
             A_tc = engine.score(Gt_rows, cohort["Gc_test"])            # [chunk, cohort]
-            t_idx = topk_rows(A_tc, k, self.nbest_discard)             # [k, chunk]
+            exact = None
+            if cohort.get("coh64") is not None:
+                Gt64, bt = self.plan.prologue_f64(engine.upload64(x_test[c0:c1]), SIDE_ENROL)
+                exact = dict(cohort["coh64"], G_rows=Gt64, bnd_rows=bt)
+            t_idx = topk_rows(A_tc, k, self.nbest_discard, exact)      # [k, chunk]
             mz, iz, ldz = gather_stats(A_ec, None, t_idx, c1 - c0, 1e-5, k)  # [enrol, chunk]
             mt, it, ldt = gather_stats(A_tc, None, e_idx, ne, 1e-5, k)       # [chunk, enrol]
             S = engine.score(Ge, Gt_cols)                              # [enrol, chunk]

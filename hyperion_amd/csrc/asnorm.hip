@@ -86,18 +86,109 @@ __device__ void select_rank(const unsigned* __restrict__ keys, int n, int want, 
     *out_gt = gt;
 }
 
+__device__ __forceinline__ float float_of_key(unsigned key) {
+    return __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
+}
+
+// Device view of hypmi_topk_exact (see hypmi.h): where the exact value of entry (row, c) comes from.
+struct ExactSrc {
+    int mode;               // 0 none, 1 fp64 matrix, 2 fp64 packed rows
+    const double* A64;      // mode 1: [n_rows x lda64]
+    int64_t lda64;
+    const double* G_rows;   // mode 2: [n_rows x ldg] rows [g, q, |g|]
+    const double* G_coh;    //         [nc x ldg]
+    int64_t ldg;
+    int K;
+    const float* bnd_rows;  // mode 2: (|g|, |q|) per row
+    float coh_gmax, coh_qmax, err_coeff;
+    unsigned long long* counters;  // [0] rows with a re-decided boundary, [1] rows skipped (too many ties)
+};
+
+constexpr int TK_CAND = 64;  // boundary candidates re-decided per boundary
+
+// Boundary re-decision.  The fp32 selection puts the boundary of "rank < R" at value thr; entries
+// within +-delta of thr (delta = what fp32 cannot resolve) are candidates.  Entries above thr+delta are
+// certainly above; m = R - (their count) candidates must be above, chosen by exact value (ties by
+// index).  Fills cand_idx / cand_above and returns the number of candidates (0 = nothing to override).
+__device__ int redecide_boundary(const unsigned* __restrict__ keys, int nc, int R, float thr, float delta,
+                                 const ExactSrc& ex, int64_t row, unsigned* hist, unsigned* bcast,
+                                 unsigned short* cand_idx, unsigned char* cand_above) {
+    const int tid = threadIdx.x;
+    double* exact = reinterpret_cast<double*>(hist);  // 64 doubles alias the 256-bin histogram
+    if (tid == 0) {
+        bcast[0] = 0;  // entries certainly above
+        bcast[1] = 0;  // candidates
+    }
+    __syncthreads();
+    const float hi = thr + delta, lo = thr - delta;
+    unsigned n_above = 0;
+    for (int i = tid; i < nc; i += TK_THREADS) {
+        const float v = float_of_key(keys[i]);
+        if (v > hi) {
+            ++n_above;
+        } else if (v >= lo) {
+            const unsigned pos = atomicAdd(&bcast[1], 1u);
+            if (pos < TK_CAND) cand_idx[pos] = (unsigned short)i;
+        }
+    }
+    if (n_above) atomicAdd(&bcast[0], n_above);
+    __syncthreads();
+    const int n_cand = (int)bcast[1];
+    const int m = R - (int)bcast[0];
+    __syncthreads();
+    if (n_cand > TK_CAND) {
+        if (tid == 0 && ex.counters) atomicAdd(&ex.counters[1], 1ull);
+        return 0;
+    }
+    if (m <= 0 || m >= n_cand) return 0;  // all candidates on one side: nothing to decide
+    // exact values of the candidates
+    if (ex.mode == 1) {
+        if (tid < n_cand) exact[tid] = ex.A64[row * ex.lda64 + cand_idx[tid]];
+    } else {
+        const int grp = tid >> 4, sub = tid & 15;
+        const double* gr = ex.G_rows + row * ex.ldg;
+        for (int a = grp; a < n_cand; a += TK_THREADS / 16) {
+            const double* gc = ex.G_coh + (int64_t)cand_idx[a] * ex.ldg;
+            double acc = 0.0;
+            for (int kk = sub; kk < ex.K; kk += 16) acc = fma(gr[kk], gc[kk], acc);
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
+            if (sub == 0) exact[a] = acc + gr[ex.K] + gc[ex.K];
+        }
+    }
+    __syncthreads();
+    if (tid < n_cand) {
+        const double v = exact[tid];
+        const unsigned short me = cand_idx[tid];
+        int rank = 0;
+        for (int b2 = 0; b2 < n_cand; ++b2) {
+            const double w = exact[b2];
+            rank += (w > v || (w == v && cand_idx[b2] < me)) ? 1 : 0;
+        }
+        cand_above[tid] = rank < m ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid == 0 && ex.counters) atomicAdd(&ex.counters[0], 1ull);
+    return n_cand;
+}
+
 // Writes the cohort indices ranked discard .. discard+k-1 of row `row`, in ascending index order,
 // into the grouped uint16 list layout; the unused tail of the last group of eight is zeroed.
+// An entry is selected iff it is above the boundary "rank < discard + k" and not above the boundary
+// "rank < discard"; rank = (#greater) + (#equal with a lower index).  With an exact source, entries
+// that fp32 cannot separate from a boundary value are re-decided from their float64 values.
 template <bool USE_LDS>
 __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float* __restrict__ A, int64_t lda,
                                                                int nc, int k, int discard,
                                                                uint16_t* __restrict__ idx8, int64_t ldi,
-                                                               unsigned* __restrict__ gkeys) {
+                                                               unsigned* __restrict__ gkeys, ExactSrc ex) {
     extern __shared__ __attribute__((aligned(16))) unsigned smem[];
-    unsigned* hist = smem;          // 256
+    unsigned* hist = smem;          // 256 (aliased by 64 doubles during boundary re-decision)
     unsigned* bcast = smem + 256;   // 4
     unsigned* wtot = smem + 260;    // 4 waves x 2 counters (+ pad)
-    unsigned* keys = USE_LDS ? smem + 272 : gkeys + (int64_t)blockIdx.x * nc;
+    unsigned short* cand_idx = reinterpret_cast<unsigned short*>(smem + 272);  // 2 x TK_CAND
+    unsigned char* cand_above = reinterpret_cast<unsigned char*>(smem + 272 + TK_CAND);  // 2 x TK_CAND
+    unsigned* keys = USE_LDS ? smem + 368 : gkeys + (int64_t)blockIdx.x * nc;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row = blockIdx.x;
     const float* src = A + row * lda;
@@ -108,22 +199,38 @@ __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float* __re
     }
     __syncthreads();
 
-    unsigned key_hi, key_lo;
-    int gt_hi, gt_lo;
-    select_rank(keys, nc, discard + k - 1, hist, bcast, &key_hi, &gt_hi);
-    if (discard > 0) {
-        select_rank(keys, nc, discard, hist, bcast, &key_lo, &gt_lo);
-    } else {
-        key_lo = 0xffffffffu;
-        gt_lo = 0;
-    }
-    // ordered compaction: rank of an element with a boundary key = (#greater) + (#equal before it)
-    int eq_hi_seen = 0, eq_lo_seen = 0, written = 0;
     const int last = discard + k;
+    unsigned key_hi, key_lo = 0xffffffffu;
+    int gt_hi, gt_lo = 0;
+    select_rank(keys, nc, last - 1, hist, bcast, &key_hi, &gt_hi);
+    if (discard > 0) select_rank(keys, nc, discard - 1, hist, bcast, &key_lo, &gt_lo);
+
+    // what fp32 cannot resolve around a boundary value
+    int n_hi = 0, n_lo = 0;
+    float thr_hi = 0.f, thr_lo = 0.f, d_hi = 0.f, d_lo = 0.f;
+    if (ex.mode != 0) {
+        thr_hi = float_of_key(key_hi);
+        thr_lo = float_of_key(key_lo);
+        if (ex.mode == 1) {  // the fp32 matrix is the rounding of the fp64 one
+            d_hi = fabsf(thr_hi) * 2.4e-7f;
+            d_lo = fabsf(thr_lo) * 2.4e-7f;
+        } else {
+            const float bound = ex.err_coeff * (ex.bnd_rows[2 * row] * ex.coh_gmax + ex.bnd_rows[2 * row + 1] +
+                                                ex.coh_qmax);
+            d_hi = d_lo = 2.f * bound;
+        }
+        n_hi = redecide_boundary(keys, nc, last, thr_hi, d_hi, ex, row, hist, bcast, cand_idx, cand_above);
+        if (discard > 0)
+            n_lo = redecide_boundary(keys, nc, discard, thr_lo, d_lo, ex, row, hist, bcast, cand_idx + TK_CAND,
+                                     cand_above + TK_CAND);
+    }
+
+    // ordered compaction
+    int eq_hi_seen = 0, eq_lo_seen = 0, written = 0;
     for (int base = 0; base < nc; base += TK_THREADS) {
         const int i = base + tid;
-        const unsigned kx = i < nc ? keys[i] : 0u;
         const bool valid = i < nc;
+        const unsigned kx = valid ? keys[i] : 0u;
         const bool is_hi = valid && kx == key_hi;
         const bool is_lo = valid && discard > 0 && kx == key_lo;
         const unsigned long long m_hi = __ballot(is_hi), m_lo = __ballot(is_lo);
@@ -146,14 +253,18 @@ __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float* __re
         }
         bool sel = false;
         if (valid) {
-            if (is_lo) {  // also covers key_lo == key_hi
-                const int rank = gt_lo + lo_before;
-                sel = rank >= discard && rank < last;
-            } else if (is_hi) {
-                sel = gt_hi + hi_before < last;
-            } else {
-                sel = kx > key_hi && kx < key_lo;
+            bool above_hi = kx > key_hi || (is_hi && gt_hi + hi_before < last);
+            bool above_lo = discard > 0 && (kx > key_lo || (is_lo && gt_lo + lo_before < discard));
+            if (n_hi | n_lo) {
+                const float v = float_of_key(kx);
+                if (n_hi && fabsf(v - thr_hi) <= d_hi)
+                    for (int a2 = 0; a2 < n_hi; ++a2)
+                        if (cand_idx[a2] == i) above_hi = cand_above[a2] != 0;
+                if (n_lo && fabsf(v - thr_lo) <= d_lo)
+                    for (int a2 = 0; a2 < n_lo; ++a2)
+                        if (cand_idx[TK_CAND + a2] == i) above_lo = cand_above[TK_CAND + a2] != 0;
             }
+            sel = above_hi && !above_lo;
         }
         __syncthreads();  // wtot is rewritten below
         const unsigned long long m_sel = __ballot(sel);
@@ -438,7 +549,7 @@ constexpr int MAX_LDS_BYTES = 160 * 1024;
 }  // namespace
 
 extern "C" int64_t hypmi_topk_workspace_bytes(int64_t n_rows, int nc) {
-    const int64_t lds_need = (272 + (int64_t)nc) * 4;
+    const int64_t lds_need = (368 + (int64_t)nc) * 4;
     return lds_need <= MAX_LDS_BYTES ? 0 : n_rows * (int64_t)nc * 4;
 }
 
@@ -447,8 +558,8 @@ extern "C" int64_t hypmi_topk_list_bytes(int k, int64_t ldi) {
 }
 
 extern "C" int hypmi_topk_rows(const float* A, int64_t n_rows, int nc, int64_t lda, int k, int discard,
-                               uint16_t* idx_t, int64_t ldi, void* workspace, int64_t workspace_bytes,
-                               void* stream_) {
+                               uint16_t* idx_t, int64_t ldi, const hypmi_topk_exact* exact, void* workspace,
+                               int64_t workspace_bytes, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     HYPMI_REQUIRE(A && idx_t, "topk_rows: null pointer");
     HYPMI_REQUIRE(n_rows >= 0 && nc > 0 && lda >= nc && ldi >= n_rows, "topk_rows: bad shape");
@@ -458,20 +569,43 @@ extern "C" int hypmi_topk_rows(const float* A, int64_t n_rows, int nc, int64_t l
     HYPMI_REQUIRE(n_rows <= 0x7fffffffLL, "topk_rows: too many rows");
     HYPMI_REQUIRE(nc <= 65536, "topk_rows: cohort of %d exceeds the 16-bit index lists", nc);
     HYPMI_REQUIRE(aligned16(idx_t), "topk_rows: index lists must be 16-byte aligned");
+    ExactSrc ex = {};
+    if (exact && exact->mode != 0) {
+        HYPMI_REQUIRE(exact->mode == 1 || exact->mode == 2, "topk_rows: unknown exact mode %d", exact->mode);
+        if (exact->mode == 1) {
+            HYPMI_REQUIRE(exact->A64 && exact->lda64 >= nc, "topk_rows: exact matrix missing or too narrow");
+        } else {
+            HYPMI_REQUIRE(exact->G_rows && exact->G_coh && exact->bnd_rows && exact->K > 0 &&
+                              exact->ldg >= exact->K + 2,
+                          "topk_rows: exact packed rows missing");
+        }
+        ex.mode = exact->mode;
+        ex.A64 = exact->A64;
+        ex.lda64 = exact->lda64;
+        ex.G_rows = exact->G_rows;
+        ex.G_coh = exact->G_coh;
+        ex.ldg = exact->ldg;
+        ex.K = exact->K;
+        ex.bnd_rows = exact->bnd_rows;
+        ex.coh_gmax = exact->coh_gmax;
+        ex.coh_qmax = exact->coh_qmax;
+        ex.err_coeff = exact->err_coeff;
+        ex.counters = exact->counters;
+    }
     if (n_rows == 0) return HYPMI_OK;
-    const int64_t lds_need = (272 + (int64_t)nc) * 4;
+    const int64_t lds_need = (368 + (int64_t)nc) * 4;
     if (lds_need <= MAX_LDS_BYTES) {
         if (lds_need > 48 * 1024)
             HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_rows_kernel<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
         hipLaunchKernelGGL(topk_rows_kernel<true>, dim3((unsigned)n_rows), dim3(TK_THREADS), lds_need,
-                           stream, A, lda, nc, k, discard, idx_t, ldi, (unsigned*)nullptr);
+                           stream, A, lda, nc, k, discard, idx_t, ldi, (unsigned*)nullptr, ex);
     } else {
         HYPMI_REQUIRE(workspace && workspace_bytes >= n_rows * (int64_t)nc * 4,
                       "topk_rows: cohort of %d needs a %lld-byte workspace", nc,
                       (long long)(n_rows * (int64_t)nc * 4));
-        hipLaunchKernelGGL(topk_rows_kernel<false>, dim3((unsigned)n_rows), dim3(TK_THREADS), 272 * 4,
-                           stream, A, lda, nc, k, discard, idx_t, ldi, static_cast<unsigned*>(workspace));
+        hipLaunchKernelGGL(topk_rows_kernel<false>, dim3((unsigned)n_rows), dim3(TK_THREADS), 368 * 4,
+                           stream, A, lda, nc, k, discard, idx_t, ldi, static_cast<unsigned*>(workspace), ex);
     }
     HYPMI_HIP(hipGetLastError());
     return HYPMI_OK;

@@ -5,9 +5,16 @@ from ..hyp_defs import float_cpu
 from .score_norm import ScoreNorm, dev_mask, dev_matrix, transpose, transpose_mask, zero_masked
 
 
-def topk_rows(A, k, discard):
+def topk_rows(A, k, discard, exact=None):
     """Device [rows, cohort] -> grouped uint16 index lists [ceil(k/8), rows, 8] (stored as int16):
-    entry j of row q at [j >> 3, q, j & 7]; cohort indices ranked discard..discard+k-1 per row."""
+    entry j of row q at [j >> 3, q, j & 7]; cohort indices ranked discard..discard+k-1 per row.
+
+    exact: optional source of float64 values used to re-decide members that fp32 cannot separate
+    from a selection boundary: {"A64": float64 device matrix A was rounded from} or
+    {"G_rows", "G_coh", "bnd_rows", "coh_gmax", "coh_qmax"} (fp64 packed rows of Plan.prologue_f64).
+    With exact["count"] = True the dict receives "counters" = (rows re-decided, rows skipped)."""
+    import ctypes
+
     torch = engine.require_gpu()
     lib = _lib.load()
     n, nc = A.shape
@@ -15,8 +22,29 @@ def topk_rows(A, k, discard):
     idx = torch.empty(((k + 7) // 8, ldi, 8), dtype=torch.int16, device=A.device)
     ws_bytes = lib.hypmi_topk_workspace_bytes(n, nc)
     ws = torch.empty(max(ws_bytes // 4, 4), dtype=torch.int32, device=A.device)
+    ex_ptr, counters = None, None
+    if exact is not None:
+        ex = _lib.TopkExact()
+        if exact.get("count"):
+            counters = torch.zeros(2, dtype=torch.int64, device=A.device)
+            ex.counters = counters.data_ptr()
+        if "A64" in exact:
+            A64 = exact["A64"]
+            assert A64.dtype == torch.float64 and tuple(A64.shape) == (n, nc) and A64.stride(1) == 1
+            ex.mode, ex.A64, ex.lda64 = 1, A64.data_ptr(), A64.stride(0)
+        else:
+            Gr, Gc = exact["G_rows"], exact["G_coh"]
+            assert Gr.shape[0] == n and Gc.shape[0] == nc and Gr.shape[1] == Gc.shape[1]
+            ex.mode, ex.G_rows, ex.G_coh = 2, Gr.data_ptr(), Gc.data_ptr()
+            ex.ldg, ex.K = Gr.stride(0), Gr.shape[1] - 2
+            ex.bnd_rows = exact["bnd_rows"].data_ptr()
+            ex.coh_gmax, ex.coh_qmax = float(exact["coh_gmax"]), float(exact["coh_qmax"])
+            ex.err_coeff = float(exact.get("err_coeff", engine.ERR_COEFF))
+        ex_ptr = ctypes.byref(ex)
     _lib.check(lib.hypmi_topk_rows(engine._ptr(A), n, nc, A.stride(0), k, discard, engine._ptr(idx),
-                                   ldi, engine._ptr(ws), ws_bytes, engine.stream_ptr()))
+                                   ldi, ex_ptr, engine._ptr(ws), ws_bytes, engine.stream_ptr()))
+    if counters is not None:
+        exact["counters"] = tuple(int(v) for v in counters.cpu())
     return idx
 
 
@@ -44,9 +72,10 @@ def gather_stats(X, mask_u8, idx, n_lists, std_floor, k):
 
 
 def adapt_s_norm_device(S, A_ec, A_tc, nbest, nbest_discard, mask_ec=None, mask_tc=None,
-                        std_floor=1e-5):
+                        std_floor=1e-5, exact_ec=None, exact_tc=None):
     """Adaptive S-norm on device matrices: S [enrol, test], A_ec [enrol, cohort], A_tc [test, cohort]
-    (already zeroed where masked).  Returns a device [enrol, test] tensor."""
+    (already zeroed where masked).  exact_ec / exact_tc: see topk_rows.  Returns a device
+    [enrol, test] tensor."""
     torch = engine.require_gpu()
     lib = _lib.load()
     ne, nt = S.shape
@@ -58,8 +87,8 @@ def adapt_s_norm_device(S, A_ec, A_tc, nbest, nbest_discard, mask_ec=None, mask_
     out = torch.empty((ne, ld), dtype=torch.float32, device=S.device)
     if ne == 0 or nt == 0:
         return out[:, :nt]
-    t_idx = topk_rows(A_tc, k, int(nbest_discard))  # per test: cohort ranked by coh-vs-test
-    e_idx = topk_rows(A_ec, k, int(nbest_discard))  # per enrol: cohort ranked by enr-vs-coh
+    t_idx = topk_rows(A_tc, k, int(nbest_discard), exact_tc)  # per test: cohort ranked by coh-vs-test
+    e_idx = topk_rows(A_ec, k, int(nbest_discard), exact_ec)  # per enrol: cohort ranked by enr-vs-coh
     mz, iz, ldz = gather_stats(A_ec, mask_ec, t_idx, nt, std_floor, k)  # [enrol, test]
     mt, it, ldt = gather_stats(A_tc, mask_tc, e_idx, ne, std_floor, k)  # [test, enrol]
     _lib.check(lib.hypmi_asnorm_apply(engine._ptr(S), S.stride(0), ne, nt, engine._ptr(mz),
@@ -99,7 +128,15 @@ class AdaptSNorm(ScoreNorm):
             m_ec = dev_mask(mask_enr_coh, EC.shape)
             EC = EC.clone() if isinstance(scores_enr_coh, torch.Tensor) else EC
             zero_masked(EC, m_ec)
-        out = adapt_s_norm_device(S, EC, transpose(CT), self.nbest, self.nbest_discard, m_ec, m_tc)
+        # the cohort scores arrive in float64 and are ranked in fp32 on the device: members whose fp32
+        # roundings collide at a selection boundary are re-decided from the float64 values
+        exact_ec = exact_tc = None
+        if m_ec is None and not isinstance(scores_enr_coh, torch.Tensor):
+            exact_ec = {"A64": engine.upload64(scores_enr_coh)}
+        if m_tc is None and not isinstance(scores_coh_test, torch.Tensor):
+            exact_tc = {"A64": engine.upload64(scores_coh_test).t().contiguous()}
+        out = adapt_s_norm_device(S, EC, transpose(CT), self.nbest, self.nbest_discard, m_ec, m_tc,
+                                  exact_ec=exact_ec, exact_tc=exact_tc)
         if isinstance(scores, torch.Tensor):
             return out
         return engine.to_host(out, float_cpu())

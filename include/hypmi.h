@@ -169,11 +169,35 @@ int hypmi_scatter_block(const float* blk, int64_t ldb, const int32_t* ri, int64_
  * List layout (uint16, groups of eight so that one 16-byte load fetches eight entries of a list):
  *   entry j of the list of row q is idx[((j >> 3) * ldi + q) * 8 + (j & 7)],  ldi >= n_rows,
  * hypmi_topk_list_bytes(k, ldi) bytes in all, 16-byte aligned.
- * Cohorts up to ~40k entries are selected inside LDS; larger ones need the workspace. */
+ * Cohorts up to ~40k entries are selected inside LDS; larger ones need the workspace.
+ *
+ * exact (optional): where the float64 value of an entry comes from.  Cohort members whose fp32 score
+ * cannot be separated from a selection boundary (about 0.05 % of rows have one; the wrong member
+ * moves every normalised score of that row by up to 1e-2) are then re-decided from exact values:
+ *   mode 1: A64 is the float64 matrix A was rounded from ([n_rows x lda64]);
+ *   mode 2: entry (r, c) = <G_rows[r,:K], G_coh[c,:K]> + G_rows[r,K] + G_coh[c,K] from the fp64 packed
+ *           rows of hypmi_prologue_f64; bnd_rows are that call's (|g|, |q|) pairs, coh_gmax / coh_qmax
+ *           their maxima over the cohort, err_coeff the fp32 error coefficient (8 * 2^-24).
+ * counters (optional, device, 2 x uint64): rows with a re-decided boundary, rows skipped because more
+ * than 64 entries tie with a boundary. */
+typedef struct {
+    int32_t mode;
+    const double* A64;
+    int64_t lda64;
+    const double* G_rows;
+    const double* G_coh;
+    int64_t ldg;
+    int32_t K;
+    const float* bnd_rows;
+    float coh_gmax, coh_qmax, err_coeff;
+    unsigned long long* counters;
+} hypmi_topk_exact;
+
 int64_t hypmi_topk_workspace_bytes(int64_t n_rows, int nc);
 int64_t hypmi_topk_list_bytes(int k, int64_t ldi);
 int hypmi_topk_rows(const float* A, int64_t n_rows, int nc, int64_t lda, int k, int discard,
-                    uint16_t* idx, int64_t ldi, void* workspace, int64_t workspace_bytes, void* stream);
+                    uint16_t* idx, int64_t ldi, const hypmi_topk_exact* exact, void* workspace,
+                    int64_t workspace_bytes, void* stream);
 
 /* Cohort statistics over selected members (adapt_s_norm.py:46-63 and 69-86): for every row r of
  * X[n_rows x nc] and list q (layout above): mean[r,q] and istd[r,q] = 1 / max(std, std_floor) of

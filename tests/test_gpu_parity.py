@@ -380,3 +380,61 @@ def test_refinement_golden_strict(golden, kind):
         s = make(kind, m).llr_1vs1(g["x1_" + tag], g["x2_" + tag])
         ref = g["%s_%s_scores" % (kind, tag)]
         assert np.max(np.abs(s - ref) / np.abs(ref)) <= 1e-4
+
+
+def test_topk_boundary_redecided_from_float64_matrix():
+    """numpy AdaptSNorm path: two cohort scores that differ by 1e-9 collide in fp32 exactly at the
+    top-k boundary; the member float64 argsort keeps must be kept (the fp32 tie rule alone would keep
+    the other one, whose enrol-vs-cohort scores are very different)."""
+    from hyperion_amd.score_norm import AdaptSNorm
+
+    rng = np.random.RandomState(12)
+    ne, nt, nc, k = 6, 40, 300, 25
+    sc = rng.randn(ne, nt) * 5
+    ct = rng.randn(nc, nt) * 4 - 6
+    ec = rng.randn(ne, nc) * 4 - 6
+    for t in range(nt):
+        order = np.argsort(-ct[:, t])
+        a, b = sorted((order[k - 1], order[k]))      # the two members around the boundary
+        v = ct[order[k - 1], t]
+        ct[a, t] = np.float32(v)                     # lower index: fp32 tie rule would keep it
+        ct[b, t] = np.float64(np.float32(v)) + 1e-9  # float64 says this one ranks higher
+    ec[:, ::2] += 40.0                               # make a wrong member visible in the statistics
+    ref = O.adapt_s_norm(sc, ct, ec, k, 0)
+    got = AdaptSNorm(nbest=k).predict(sc, ct, ec)
+    err = np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)
+    assert err.max() <= 2e-5, err.max()
+
+
+def test_topk_boundary_redecided_from_packed_rows():
+    """Device pipeline: a cohort of near-duplicate vectors puts pairs of fp32-indistinguishable
+    scores at the selection boundary of most rows.  With the fp64 packed rows as exact source the
+    selected sets equal those of float64 argsort in every row; without it they do not."""
+    import synth
+    from hyperion_amd import engine
+    from hyperion_amd.engine import SIDE_ENROL, SIDE_TEST
+    from hyperion_amd.score_norm.adapt_s_norm import lists_to_numpy, topk_rows
+
+    m = synth.make_splda(64, 20)
+    model = make("splda", m)
+    rng = np.random.RandomState(1)
+    base = synth.length_norm(synth.sample_splda(m, 500, 1, seed=5))
+    xc = np.vstack([base, base * (1 + 2e-8 * rng.randn(500, 1)) + 1e-8 * rng.randn(500, 64)])
+    xt = synth.length_norm(synth.sample_splda(m, 300, 1, seed=6))
+    plan = model.score_plan()
+    k, disc = 120, 7
+    A = engine.score(plan.prologue(engine.upload(xt), SIDE_ENROL), plan.prologue(engine.upload(xc), SIDE_TEST))
+    ref_scores = O.llr_1vs1(m, xt, xc)
+    order = np.lexsort((np.arange(1000)[None, :].repeat(300, 0), -ref_scores), axis=1)
+    want = np.sort(order[:, disc:disc + k], axis=1)
+    Gt, bt = plan.prologue_f64(engine.upload64(xt), SIDE_ENROL)
+    Gc, bc = plan.prologue_f64(engine.upload64(xc), SIDE_TEST)
+    exact = {"G_rows": Gt, "G_coh": Gc, "bnd_rows": bt, "coh_gmax": float(bc[:, 0].max()),
+             "coh_qmax": float(bc[:, 1].max()), "count": True}
+    got = lists_to_numpy(topk_rows(A, k, disc, exact), k)
+    plain = lists_to_numpy(topk_rows(A, k, disc), k)
+    bad_exact = int((got != want).any(axis=1).sum())
+    bad_plain = int((plain != want).any(axis=1).sum())
+    assert bad_plain > 10, bad_plain      # the test bites: fp32 alone picks wrong members
+    assert bad_exact == 0, (bad_exact, exact["counters"])
+    assert exact["counters"][0] > 0 and exact["counters"][1] == 0
