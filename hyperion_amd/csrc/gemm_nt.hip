@@ -5,99 +5,34 @@
 // kernel in score.hip.  Both operands are K-contiguous, so each lane fetches four consecutive k of
 // one row with a single 16-byte LDS read and feeds them to four v_mfma_f32_32x32x2_f32 steps.
 //
-// Tile: 128 x 128 outputs per 256-thread workgroup, 64 x 64 per wave (2 x 2 MFMA tiles),
-// K consumed in steps of 32 through LDS (row stride 36 floats: conflict-free 16-byte reads),
-// next step's global loads issued before the current step's MFMAs.
-#include "common.h"
+// Tile: 128 x 128 outputs per 256-thread workgroup, 64 x 64 per wave (2 x 2 MFMA tiles); the main
+// loop is shared with the fused prologue kernel (gemm_tile.h).
+#include "gemm_tile.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 4;
-
-__device__ __forceinline__ float4 ld4_guard(const float* p, bool ok) {
-    return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
-}
+constexpr int BM = 128, BN = 128;
 
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda,
                                                       const float* __restrict__ B, int64_t ldb,
                                                       const float* __restrict__ bias,
                                                       float* __restrict__ C, int64_t ldc, int64_t M,
                                                       int64_t N, int K) {
-    __shared__ __attribute__((aligned(16))) float As[BM * LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int wr = wave >> 1, wc = wave & 1;
+    __shared__ __attribute__((aligned(16))) float smem[gemm_tile::Shape<2, 2>::SMEM_FLOATS];
     const int64_t m0 = (int64_t)blockIdx.y * BM;
     const int64_t n0 = (int64_t)blockIdx.x * BN;
-
-    const int lrow = tid >> 3;       // 0..31 (+32 per pass)
-    const int lk = (tid & 7) * 4;    // float offset inside the K step
-
     f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    float4 ra[4], rb[4];
-    auto fetch = [&](int k0) {
-        const bool kok = (k0 + lk) < K;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t gm = m0 + lrow + 32 * i;
-            const int64_t gn = n0 + lrow + 32 * i;
-            ra[i] = ld4_guard(A + gm * lda + k0 + lk, kok && gm < M);
-            rb[i] = ld4_guard(B + gn * ldb + k0 + lk, kok && gn < N);
-        }
-    };
-
-    fetch(0);
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float4*>(&As[(lrow + 32 * i) * LDT + lk]) = ra[i];
-            *reinterpret_cast<float4*>(&Bs[(lrow + 32 * i) * LDT + lk]) = rb[i];
-        }
-        __syncthreads();
-        if (k0 + BK < K) fetch(k0 + BK);
-#pragma unroll
-        for (int s = 0; s < BK / 8; ++s) {
-            float4 a[2], b[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                a[t] = *reinterpret_cast<const float4*>(&As[(wr * 64 + 32 * t + r) * LDT + 8 * s + 4 * h]);
-                b[t] = *reinterpret_cast<const float4*>(&Bs[(wc * 64 + 32 * t + r) * LDT + 8 * s + 4 * h]);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const float av = e == 0 ? a[i].x : e == 1 ? a[i].y : e == 2 ? a[i].z : a[i].w;
-                        const float bv = e == 0 ? b[j].x : e == 1 ? b[j].y : e == 2 ? b[j].z : b[j].w;
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
-                    }
-            }
-        }
-    }
-
-    // D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    gemm_tile::zero<2, 2>(acc);
+    gemm_tile::mainloop<2, 2>(A, lda, B, ldb, m0, n0, M, N, K, smem, acc);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int64_t col = n0 + wc * 64 + 32 * j + r;
+        const int64_t col = n0 + gemm_tile::col_of<2>(j);
         const float bv = (bias != nullptr && col < N) ? bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int64_t row = m0 + wr * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int64_t row = m0 + gemm_tile::row_of<2>(i, e);
                 if (row < M && col < N) C[row * ldc + col] = acc[i][j][e] + bv;
             }
         }

@@ -22,10 +22,33 @@ struct Segment {
     }
 };
 
+// Last length-normalised segment folded with the PLDA projection (one kernel, see prologue.hip):
+//   u = x A1 + b1 (n_u columns, only its row norm is needed), v = x (A1 A2) + b1 A2 (n_v = 2K columns),
+//   z = sqrt(n_norm) / (|u| + 1e-10) * v + b2.   Wcat = [A1 | A1 A2]^T, [n_u + n_v] x ldw.
+struct FusedTail {
+    bool enabled = false;
+    float* Wcat = nullptr;
+    float* bias_u = nullptr;    // b1, n_u entries (nullptr = 0)
+    float* bias_vin = nullptr;  // b1 A2, n_v entries (nullptr = 0)
+    int64_t ldw = 0;
+    int n_u = 0, n_v = 0, d_in = 0;
+    float sqrt_dn = 0.f;        // sqrt of the normalised dimension
+    bool norm_from_input = false;  // identity A1: |u| is the norm of the input row (+ b1)
+
+    void release() {
+        if (Wcat) (void)hipFree(Wcat);
+        if (bias_u) (void)hipFree(bias_u);
+        if (bias_vin) (void)hipFree(bias_vin);
+        Wcat = bias_u = bias_vin = nullptr;
+        enabled = false;
+    }
+};
+
 struct hypmi_plan {
     int d_in = 0, n_seg = 0, d_last = 0, K = 0, KP = 0;
     Segment seg[HYPMI_MAX_SEG];
     Segment fin;  // [At | An]^T, 2K outputs
+    FusedTail fused;
     double c = 0.0;
     int max_dim = 0;
 };

@@ -1,15 +1,17 @@
 // Plans (device-resident folded models) and the embedding prologue:
 //   x -> [affine (+ length norm)]* -> (g, h) = y [At | An] + [bt | bn] -> packed row
 //   [g, q, 1] or [g, 1, q + c],  q = (|g|^2 - |h|^2) / 2.
-// The affine steps run on the matrix cores (gemm_nt.hip); the row-wise steps are one wavefront per
-// embedding with fp64 wave reductions (the norms and q feed every score of that row, so they are
-// accumulated in double even though the data is fp32).
+// The last length-normalised segment and the projection run as ONE kernel (prologue_fused_kernel:
+// the normalised intermediate never leaves the chip); earlier segments, if any, are a GEMM
+// (gemm_nt.hip) plus a row kernel each.  q is accumulated in double by the packing kernel, because it
+// feeds every score of its row.
 #include <stdarg.h>
 #include <string.h>
 
 #include <vector>
 
 #include "common.h"
+#include "gemm_tile.h"
 
 // ------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -76,6 +78,7 @@ extern "C" void hypmi_plan_destroy(hypmi_plan* p) {
         p->seg[i].release();
     }
     p->fin.release();
+    p->fused.release();
     delete p;
 }
 
@@ -135,6 +138,48 @@ extern "C" int hypmi_plan_create(const hypmi_plan_desc* d, hypmi_plan** out) {
         rc = upload_transposed(W.data(), cur, 2 * K, &p->fin);
         if (rc == HYPMI_OK) rc = upload_vec(b.data(), 2 * K, &p->fin);
         p->KP = hypmi_kp_for_k(K);
+        // fold the last length-normalised segment into the projection
+        if (rc == HYPMI_OK && d->n_seg > 0 && d->seg[d->n_seg - 1].lnorm) {
+            const hypmi_segment& ls = d->seg[d->n_seg - 1];
+            const int dp = p->seg[d->n_seg - 1].d_in;  // input dim of that segment
+            const int D1 = cur, NV = 2 * K;
+            FusedTail& f = p->fused;
+            f.d_in = dp;
+            f.n_u = ls.A ? D1 : 0;
+            f.n_v = NV;
+            f.sqrt_dn = (float)sqrt((double)D1);
+            f.norm_from_input = ls.A == nullptr;
+            f.ldw = round_up(dp, 4);
+            std::vector<float> wc((size_t)(f.n_u + NV) * f.ldw, 0.f);
+            std::vector<float> bv(NV, 0.f);
+            std::vector<double> col(dp);
+            for (int j = 0; j < f.n_u; ++j)
+                for (int i = 0; i < dp; ++i) wc[(size_t)j * f.ldw + i] = (float)ls.A[(size_t)i * D1 + j];
+            for (int j = 0; j < NV; ++j) {
+                // column j of A1 A2 (A1 = identity when the segment has no matrix)
+                double bacc = 0.0;
+                if (ls.A) {
+                    for (int i = 0; i < dp; ++i) {
+                        double acc = 0.0;
+                        for (int t = 0; t < D1; ++t) acc += ls.A[(size_t)i * D1 + t] * W[(size_t)t * NV + j];
+                        col[i] = acc;
+                    }
+                } else {
+                    for (int i = 0; i < dp; ++i) col[i] = W[(size_t)i * NV + j];
+                }
+                if (ls.b)
+                    for (int t = 0; t < D1; ++t) bacc += ls.b[t] * W[(size_t)t * NV + j];
+                bv[j] = (float)bacc;
+                for (int i = 0; i < dp; ++i) wc[(size_t)(f.n_u + j) * f.ldw + i] = (float)col[i];
+            }
+            rc = to_device(wc, &f.Wcat);
+            if (rc == HYPMI_OK && ls.b) {
+                std::vector<float> bu(ls.b, ls.b + D1);
+                rc = to_device(bu, &f.bias_u);
+                if (rc == HYPMI_OK) rc = to_device(bv, &f.bias_vin);
+            }
+            f.enabled = rc == HYPMI_OK;
+        }
     }
     if (rc != HYPMI_OK) {
         hypmi_plan_destroy(p);
@@ -203,6 +248,122 @@ __global__ __launch_bounds__(256) void pack_gq_kernel(const float* __restrict__ 
     }
 }
 
+// Fused tail of the prologue: affine + length norm + PLDA projection in one pass over the rows.
+// A workgroup owns 64*TM rows.  It first walks the n_u columns of u = x A1 + b1 in 128-column
+// chunks, keeping only per-row sums of squares (u never leaves the chip), turns them into the
+// per-row scale, then walks the 2K columns of v = x (A1 A2) + b1 A2 and writes
+// z = scale * v + b2 = [g | h].
+template <int TM>
+__global__ __launch_bounds__(256) void prologue_fused_kernel(
+    const float* __restrict__ x, int64_t ldx, int64_t n, int d_in, const float* __restrict__ Wcat,
+    int64_t ldw, const float* __restrict__ bias_u, const float* __restrict__ bias_vin,
+    const float* __restrict__ bias_vout, int n_u, int n_v, float sqrt_dn, int norm_from_input,
+    float* __restrict__ Z, int64_t ldz) {
+    constexpr int BM = 64 * TM;
+    __shared__ __attribute__((aligned(16))) float smem[gemm_tile::Shape<TM, 2>::SMEM_FLOATS];
+    __shared__ float rowsq[2][BM];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, wc = wave & 1;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    f32x16 acc[TM][2];
+
+    float ss[TM][16];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ss[i][e] = 0.f;
+    for (int n0 = 0; n0 < n_u; n0 += 128) {
+        gemm_tile::zero<TM, 2>(acc);
+        gemm_tile::mainloop<TM, 2>(x, ldx, Wcat, ldw, m0, n0, n, n_u, d_in, smem, acc);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + gemm_tile::col_of<2>(j);
+            const bool ok = col < n_u;
+            const float bu = (ok && bias_u) ? bias_u[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = ok ? acc[i][j][e] + bu : 0.f;
+                    ss[i][e] = fmaf(v, v, ss[i][e]);
+                }
+        }
+    }
+    if (norm_from_input) {
+        // identity matrix: |u| is the norm of the input row itself (plus the bias, if any)
+        for (int rr = wave; rr < BM; rr += 4) {
+            const int64_t row = m0 + rr;
+            float a2 = 0.f;
+            if (row < n)
+                for (int kk = lane; kk < d_in; kk += 64) {
+                    const float v = x[row * ldx + kk] + (bias_u ? bias_u[kk] : 0.f);
+                    a2 = fmaf(v, v, a2);
+                }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) a2 += __shfl_xor(a2, off, 64);
+            if (lane == 0) {
+                rowsq[0][rr] = a2;
+                rowsq[1][rr] = 0.f;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = ss[i][e];
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);  // the 32 columns of a half
+                if (r == 0) rowsq[wc][gemm_tile::row_of<TM>(i, e)] = v;
+            }
+    }
+    __syncthreads();
+    float sc[TM][16];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int rr = gemm_tile::row_of<TM>(i, e);
+            sc[i][e] = sqrt_dn / (sqrtf(rowsq[0][rr] + rowsq[1][rr]) + 1e-10f);
+        }
+    const float* Wv = Wcat + (int64_t)n_u * ldw;
+    for (int n0 = 0; n0 < n_v; n0 += 128) {
+        gemm_tile::zero<TM, 2>(acc);
+        gemm_tile::mainloop<TM, 2>(x, ldx, Wv, ldw, m0, n0, n, n_v, d_in, smem, acc);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + gemm_tile::col_of<2>(j);
+            if (col < n_v) {
+                const float bi = bias_vin ? bias_vin[col] : 0.f;
+                const float bo = bias_vout ? bias_vout[col] : 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int64_t row = m0 + gemm_tile::row_of<TM>(i, e);
+                        if (row < n) Z[row * ldz + col] = fmaf(sc[i][e], acc[i][j][e] + bi, bo);
+                    }
+            }
+        }
+    }
+}
+
+int run_fused_tail(const hypmi_plan* p, const float* in, int64_t ldin, int64_t rows, float* Z, int64_t ldz,
+                   hipStream_t stream) {
+    const FusedTail& f = p->fused;
+    if (rows >= 128 * 2048) {
+        hipLaunchKernelGGL(prologue_fused_kernel<2>, dim3((unsigned)((rows + 127) / 128)), dim3(256), 0, stream,
+                           in, ldin, rows, f.d_in, f.Wcat, f.ldw, f.bias_u, f.bias_vin, p->fin.bias, f.n_u,
+                           f.n_v, f.sqrt_dn, f.norm_from_input ? 1 : 0, Z, ldz);
+    } else {
+        hipLaunchKernelGGL(prologue_fused_kernel<1>, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, stream, in,
+                           ldin, rows, f.d_in, f.Wcat, f.ldw, f.bias_u, f.bias_vin, p->fin.bias, f.n_u, f.n_v,
+                           f.sqrt_dn, f.norm_from_input ? 1 : 0, Z, ldz);
+    }
+    HYPMI_HIP(hipGetLastError());
+    return HYPMI_OK;
+}
+
 int run_lnorm(float* y, int64_t n, int64_t ldy, int d, hipStream_t stream) {
     if (n == 0) return HYPMI_OK;
     hipLaunchKernelGGL(lnorm_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, y, n, ldy, d);
@@ -234,16 +395,16 @@ int carve(const hypmi_plan* p, int64_t n, void* ws, int64_t ws_bytes, Work* w) {
 // Runs the segments on `rows` rows starting at x.  On return *cur / *ldcur describe where the result
 // lives (x itself when the chain is empty).  If `final_out` is given, the last materialising step
 // writes straight into it.
-int run_segments(const hypmi_plan* p, const float* x, int64_t ldx, int64_t rows, const Work& w,
+int run_segments(const hypmi_plan* p, int n_run, const float* x, int64_t ldx, int64_t rows, const Work& w,
                  float* final_out, int64_t ld_final, const float** cur, int64_t* ldcur,
                  hipStream_t stream) {
     const float* in = x;
     int64_t ldin = ldx;
     int which = 0;
     int last_mat = -1;  // last segment that has to write a buffer
-    for (int i = 0; i < p->n_seg; ++i)
+    for (int i = 0; i < n_run; ++i)
         if (p->seg[i].Wt || p->seg[i].lnorm) last_mat = i;
-    for (int i = 0; i < p->n_seg; ++i) {
+    for (int i = 0; i < n_run; ++i) {
         const Segment& s = p->seg[i];
         if (!s.Wt && !s.lnorm) continue;
         const bool to_final = final_out && i == last_mat;
@@ -310,10 +471,15 @@ extern "C" int hypmi_prologue(const hypmi_plan* p, const float* x, int64_t n, in
         const int64_t rows = (n - r0 < w.rows) ? n - r0 : w.rows;
         const float* cur;
         int64_t ldcur;
-        rc = run_segments(p, x + r0 * ldx, ldx, rows, w, nullptr, 0, &cur, &ldcur, stream);
+        const bool fuse = p->fused.enabled;
+        rc = run_segments(p, fuse ? p->n_seg - 1 : p->n_seg, x + r0 * ldx, ldx, rows, w, nullptr, 0, &cur,
+                          &ldcur, stream);
         if (rc != HYPMI_OK) return rc;
-        rc = hypmi_launch_gemm_nt(cur, ldcur, p->fin.Wt, p->fin.ldw, p->fin.bias, w.z, w.ldz, rows,
-                                  2 * p->K, p->fin.d_in, stream);
+        if (fuse)
+            rc = run_fused_tail(p, cur, ldcur, rows, w.z, w.ldz, stream);
+        else
+            rc = hypmi_launch_gemm_nt(cur, ldcur, p->fin.Wt, p->fin.ldw, p->fin.bias, w.z, w.ldz, rows,
+                                      2 * p->K, p->fin.d_in, stream);
         if (rc != HYPMI_OK) return rc;
         hipLaunchKernelGGL(pack_gq_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, w.z,
                            rows, w.ldz, p->K, p->KP, side, p->c, G + r0 * p->KP);
@@ -337,7 +503,7 @@ extern "C" int hypmi_transform(const hypmi_plan* p, const float* x, int64_t n, i
         const int64_t rows = (n - r0 < w.rows) ? n - r0 : w.rows;
         const float* cur;
         int64_t ldcur;
-        rc = run_segments(p, x + r0 * ldx, ldx, rows, w, y + r0 * ldy, ldy, &cur, &ldcur, stream);
+        rc = run_segments(p, p->n_seg, x + r0 * ldx, ldx, rows, w, y + r0 * ldy, ldy, &cur, &ldcur, stream);
         if (rc != HYPMI_OK) return rc;
         if (cur != y + r0 * ldy) {  // empty chain: plain copy
             HYPMI_HIP(hipMemcpy2DAsync(y + r0 * ldy, ldy * sizeof(float), cur, ldcur * sizeof(float),
