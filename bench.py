@@ -5,7 +5,8 @@
 
 One "step" = one pass of the hot path over one batch of synthetic x-vectors that are already
 resident in HBM: embedding prologue (pre-processing chain + PLDA projection) for the enrol and the
-test side, then the full trial score matrix (kept on the device).  With N > 1 every rank scores the
+test side, conversion of the packed rows to three-way bf16 splits, then the full trial score matrix
+(kept on the device).  With N > 1 every rank scores the
 same enrol set against its own shard of test vectors (row-wise test sharding, no data-path
 collective): per-GPU work is fixed, so scaling is "weak" and the reported value is the number of
 scores all ranks produced divided by the slowest rank's time.
@@ -24,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (256 CU x 256 flop/clk x 2.4 GHz)
+BF16_MFMA_PEAK_TFLOPS = 2516.6  # dense bf16 matrix peak (256 CU x 4096 flop/clk x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
 
 WORKLOADS = {
@@ -98,6 +100,18 @@ def cpu_baseline(cfg, chain, model, sample):
     return {"value": n * n / dt, "unit": "scores/s", "cores": int(cores), "kind": "port",
             "sample": "%d x %d trials (chain on 2 x %d vectors + SPLDA llr_1vs1), float64 numpy, %.2f s"
                       % (n, n, n, dt)}
+
+
+def profiled_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 counter passes
+    (FETCH_SIZE / WRITE_SIZE, corrected; see tools/summarize_prof.py), or None when no profile of
+    this workload has been recorded.  Counters cannot be read from inside the timed run."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def asnorm_stage(plda, preproc, cfg, n_test, steps, warmup, rank, world=1):
@@ -193,18 +207,22 @@ def main():
 
     ev_pairs = []
 
+    use_split = engine.split_rows(plan.prologue(x1[:1], SIDE_ENROL)) is not None
+
     def step(record):
         G1 = plan.prologue(x1, SIDE_ENROL)
         G2 = plan.prologue(x2, SIDE_TEST)
+        if use_split:  # bf16 matrix cores at fp32 accuracy
+            G1, G2 = engine.split_rows(G1), engine.split_rows(G2)
         if record:
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-            engine.score(G1, G2, out=S)
+            engine.score(G1, G2, out=S, split=False)
             e1.record()
             ev_pairs.append((e0, e1))
         else:
-            engine.score(G1, G2, out=S)
+            engine.score(G1, G2, out=S, split=False)
 
     for _ in range(args.warmup):
         step(False)
@@ -230,6 +248,8 @@ def main():
     value = scores_per_step * args.steps / dt
     K = cfg["K"]
     achieved_tflops = 2.0 * K * n1 * n2 / (score_ms * 1e-3) / 1e12
+    # the split kernel executes 6 bf16 partial products per fp32 product over the K + 2 packed columns
+    executed_tflops = 6 * 2.0 * (K + 2) * n1 * n2 / (score_ms * 1e-3) / 1e12
 
     out = {
         "metric": "PLDA trial scores/sec (512-d, SPLDA)",
@@ -252,17 +272,27 @@ def main():
             "parallelism": "test rows sharded over %d GPU(s), enrol replicated" % world,
         },
         "roofline": {
-            "kernel": "score_rs_kernel<%d,2>" % plan.kp,
+            "kernel": ("score_split_kernel<%d,1>" % ((plan.kp + 15) // 16)) if use_split
+                      else "score_rs_kernel<%d,2>" % plan.kp,
             "bound": "mfma",
             "achieved": achieved_tflops,
             "peak": FP32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved_tflops / FP32_MFMA_PEAK_TFLOPS,
-            "traffic": None,
+            "traffic": profiled_traffic(args.workload),
             "avg_launch_ms": score_ms,
             "algorithmic_flops_per_launch": 2.0 * K * n1 * n2,
+            "note": "algorithmic fp32 flops (2 K per score) against the fp32 matrix peak; above 1 because "
+                    "the products run on the bf16 matrix cores as exact three-way splits" if use_split
+                    else "fp32 matrix cores",
+            "hbm_store_GBs": 4.0 * n1 * n2 / (score_ms * 1e-3) / 1e9,
         },
     }
+    if use_split:
+        out["roofline"]["executed"] = {
+            "pipe": "bf16 MFMA (6 partial products per fp32 product, K + 2 packed columns)",
+            "achieved": executed_tflops, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": executed_tflops / BF16_MFMA_PEAK_TFLOPS}
 
     if rank == 0 and not args.no_check:
         # parity spot check outside the timed region: a slab of the device matrix vs the oracle

@@ -18,30 +18,9 @@
 // workgroup or per tile half, four waves per SIMD (RT = 1) and 16-byte stores were all within 1.5 %.
 // The k order inside one 16-byte read is shared by both operands (lane half h owns k = 8s+4h+e),
 // which is all an inner product needs.
-#include "common.h"
+#include "score_tile.h"
 
 namespace hypmi_detail {
-
-// Stores a (32*RT) x 32 accumulator block through one buffer descriptor: the row offsets are scalar
-// (soffset), the lane part is one 32-bit voffset, so a store costs one SALU instruction and the store.
-// The buffer builtins exist only in the device pass of the compiler.
-template <int RT>
-__device__ __forceinline__ void store_tile_buffer(const f32x16 (&acc)[RT], float* tile_base, unsigned ldo,
-                                                  unsigned voff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned span = (unsigned)(32 * RT) * ldo * 4u;
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile_base, 0, span, 0x00020000);
-    const int vb = (int)(voff * 4u);
-    const int row_bytes = (int)ldo * 4;
-#pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int rr = 32 * t + (e & 3) + 8 * (e >> 2);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][e]), rsrc, vb, rr * row_bytes, 2);
-        }
-#endif
-}
 
 template <int KP, int RT>
 __global__ __launch_bounds__(256, 2) void score_rs_kernel(const float* __restrict__ G1,
@@ -77,9 +56,8 @@ __global__ __launch_bounds__(256, 2) void score_rs_kernel(const float* __restric
     const int64_t g2_f4 = n2 * (KP / 4);  // valid float4 count of G2
     const float4* G2v = reinterpret_cast<const float4*>(G2);
 
-    // LDS-DMA of tile `it` into buffer `buf`: instruction q covers float4 [64 q, 64 q + 64).
-    // Issued through inline asm so that the compiler neither counts it nor drains it with a
-    // vmcnt(0) in front of the LDS reads; the wait is placed by hand below.
+    // LDS-DMA of tile `it` into buffer `buf`: instruction q covers float4 [64 q, 64 q + 64);
+    // the wait for it is placed by hand below.
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)tile;
     auto stage = [&](int it, int buf) {
         const int64_t base = (tile0 + it) * TILE_F4;
@@ -90,13 +68,7 @@ __global__ __launch_bounds__(256, 2) void score_rs_kernel(const float* __restric
                 int64_t src = base + q * 64 + lane;
                 if (src > g2_f4 - 1) src = g2_f4 - 1;  // last tile may be short: re-read a valid row
                 const unsigned dst = lds_base + (unsigned)(buf * TILE_F4 + q * 64) * 16u;
-                unsigned keep;
-                asm volatile(
-                    "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                    "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                    : "=&s"(keep)
-                    : "v"(G2v + src), "s"(dst)
-                    : "memory");
+                lds_dma_16(G2v + src, dst);
             }
         }
     };
@@ -168,31 +140,6 @@ __global__ __launch_bounds__(256, 2) void score_rs_kernel(const float* __restric
             }
         }
     }
-}
-
-struct LaunchGeom {
-    int64_t gx, gy;
-    int tiles_per_chunk;
-};
-
-// enough workgroups to fill 256 CUs several times over, but long enough streams that loading the
-// stationary rows (one pass over rows_per_wg * KP floats) stays a small fraction
-static int launch_geometry(int64_t n1, int64_t n2, int rows_per_wg, LaunchGeom* g) {
-    const int64_t gx = (n1 + rows_per_wg - 1) / rows_per_wg;
-    const int64_t ntiles = (n2 + 31) / 32;
-    int64_t tiles_per_chunk = 64;
-    while (tiles_per_chunk > 8 && gx * ((ntiles + tiles_per_chunk - 1) / tiles_per_chunk) < 2048)
-        tiles_per_chunk /= 2;
-    int64_t gy = (ntiles + tiles_per_chunk - 1) / tiles_per_chunk;
-    while (gy > 65535) {
-        tiles_per_chunk *= 2;
-        gy = (ntiles + tiles_per_chunk - 1) / tiles_per_chunk;
-    }
-    HYPMI_REQUIRE(gx <= 0x7fffffffLL, "score: too many enrol rows");
-    g->gx = gx;
-    g->gy = gy;
-    g->tiles_per_chunk = (int)tiles_per_chunk;
-    return HYPMI_OK;
 }
 
 // One plain launcher per instantiation.  The tile buffers are static LDS (up to 76 KiB at KP = 304),

@@ -1,0 +1,376 @@
+// Trial score matrix on the gfx950 bf16 matrix cores at fp32 accuracy.
+//
+// Every fp32 value of a packed row is written as the exact sum of three bf16 numbers
+// x = x0 + x1 + x2 (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1); 3 x 8 significand bits
+// plus the signs of the residuals cover the 24 bits of an fp32).  The inner product of two rows is
+// then the sum of nine bf16 products per coordinate, of which the three smallest (x1 y2, x2 y1,
+// x2 y2 <= 2^-27 |x y|, below the rounding of an fp32 product chain) are dropped:
+//     x y  ~=  x0 y0  +  (x0 y1 + x1 y0)  +  (x1 y1 + x0 y2 + x2 y0)
+// bf16 x bf16 products are exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so six
+// of these MFMAs replace eight fp32 MFMAs at 16 times the rate per instruction-flop: 2.7 times the
+// arithmetic throughput of the fp32 kernel in score.hip at the same accuracy.  The three magnitude
+// classes are accumulated separately and added once per tile, smallest first.
+//
+// Split rows (hypmi_split_rows): one row = 6*KS + 1 slots of 16 bytes, KS = ceil(KP / 16); slot
+// (3 ks + s) * 2 + h holds split s of coordinates 16 ks + 8 h .. + 7, which is exactly what lane
+// half h feeds to the MFMA of k-step ks.  The last slot is padding: an odd number of slots per row
+// makes the 16 lanes of every ds_read_b128 group hit 16 different 16-byte bank slots.
+//
+// The kernel has the structure of score_rs_kernel: the split rows of 32*RT enrol vectors stay in
+// registers for the life of a wave, test rows stream through two LDS buffers by LDS-DMA in tiles of
+// 32 rows, and a tile's scores leave through one buffer descriptor.
+#include "score_tile.h"
+#include <type_traits>
+
+namespace hypmi_detail {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned bf16_rn_bits(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// x -> (x0, x1, x2) as bf16 bit patterns.  Non-finite values keep their class in x0 alone.
+__device__ __forceinline__ void split3(float x, unsigned& b0, unsigned& b1, unsigned& b2) {
+    const unsigned u = __float_as_uint(x);
+    if ((u & 0x7f800000u) == 0x7f800000u) {
+        b0 = (u >> 16) | ((u & 0x007fffffu) ? 0x40u : 0u);
+        b1 = b2 = 0;
+        return;
+    }
+    b0 = bf16_rn_bits(x);
+    if ((b0 & 0x7f80u) == 0x7f80u) {  // rounded up to infinity: stay finite
+        b0 -= 1;
+    }
+    const float r1 = x - __uint_as_float(b0 << 16);
+    b1 = bf16_rn_bits(r1);
+    const float r2 = r1 - __uint_as_float(b1 << 16);
+    b2 = bf16_rn_bits(r2);
+}
+
+// One thread per (row, k-step, lane half): 8 coordinates -> 3 slots.
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ G, int64_t n, int kp,
+                                                         int ks_total, uint4* __restrict__ H) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int per_row = 2 * ks_total;
+    const int64_t row = idx / per_row;
+    if (row >= n) return;
+    const int rem = (int)(idx - row * per_row);
+    const int ks = rem >> 1, h = rem & 1;
+    const int k0 = 16 * ks + 8 * h;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    const float* src = G + row * kp + k0;
+    if (k0 < kp) {  // kp is a multiple of 8: all eight or none
+        const float4 lo = *reinterpret_cast<const float4*>(src);
+        const float4 hi = *reinterpret_cast<const float4*>(src + 4);
+        v[0] = lo.x, v[1] = lo.y, v[2] = lo.z, v[3] = lo.w;
+        v[4] = hi.x, v[5] = hi.y, v[6] = hi.z, v[7] = hi.w;
+    }
+    unsigned b[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split3(v[j], b[0][j], b[1][j], b[2][j]);
+    const int row_slots = 6 * ks_total + 1;
+    uint4* out = H + row * row_slots;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        uint4 w;
+        w.x = b[s][0] | (b[s][1] << 16);
+        w.y = b[s][2] | (b[s][3] << 16);
+        w.z = b[s][4] | (b[s][5] << 16);
+        w.w = b[s][6] | (b[s][7] << 16);
+        out[(3 * ks + s) * 2 + h] = w;
+    }
+    if (rem == 0) out[row_slots - 1] = make_uint4(0, 0, 0, 0);
+}
+
+// LDS-DMA piece with a wave-uniform source: lane copies the 16 bytes at sbase + voff to LDS address
+// lds_dst + 16 * lane (no per-lane address arithmetic; see lds_dma_16 for why it is inline asm).
+__device__ __forceinline__ void lds_dma_16_uniform(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
+
+// Tile loop.  In a "steady" wave (all of its rows and all columns of its chunk exist) nothing but
+// MFMAs depends on the MFMAs of the current tile: the LDS-DMA of the next tile and the stores of the
+// PREVIOUS tile's scores are spread between the MFMA pairs of the current one, so the matrix pipe
+// only pauses for the three-way sum at the end of a tile.  Other waves take the plain order
+// (stage, multiply, guarded stores).
+template <int KS, int RT>
+__global__ __launch_bounds__(256, 2) void score_split_kernel(const uint4* __restrict__ H1,
+                                                             const uint4* __restrict__ H2,
+                                                             float* __restrict__ S, int64_t n1,
+                                                             int64_t n2, int64_t ldo,
+                                                             int tiles_per_chunk) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int ROW_SLOTS = 6 * KS + 1;
+    constexpr int TILE_SLOTS = 32 * ROW_SLOTS;
+    constexpr int PIECES = (TILE_SLOTS + 63) / 64;  // LDS-DMA instructions per tile
+    constexpr int BUF_SLOTS = PIECES * 64;          // the last piece runs past the tile (see hypmi_split_bytes)
+    constexpr int NPW = (PIECES + 3) / 4;           // pieces per wave
+    __shared__ __attribute__((aligned(16))) uint4 tile[2 * BUF_SLOTS];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t i0 = (int64_t)blockIdx.x * (128 * RT) + wave * (32 * RT);
+
+    // stationary operand: a[t][s][ks] = split s of H1[i0 + 32 t + r], coordinates 16 ks + 8 h .. + 7
+    bf16x8 a[RT][3][KS];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        int64_t row = i0 + 32 * t + r;
+        if (row > n1 - 1) row = n1 - 1;
+        const uint4* p = H1 + row * ROW_SLOTS + h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) a[t][s][ks] = __builtin_bit_cast(bf16x8, p[(3 * ks + s) * 2]);
+    }
+
+    const int64_t tile0 = (int64_t)blockIdx.y * tiles_per_chunk;
+    const int64_t ntiles_all = (n2 + 31) / 32;
+    int ntiles = tiles_per_chunk;
+    if (tile0 + ntiles > ntiles_all) ntiles = (int)(ntiles_all - tile0);
+    if (ntiles <= 0) return;
+    const int64_t h2_slots = n2 * ROW_SLOTS;  // valid slots of H2
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)tile;
+    const unsigned lane16 = (unsigned)lane * 16u;
+
+    // D layout: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); the row part of
+    // a store address is wave-uniform (soffset), the lane part is one 32-bit voffset.
+    const int vb = (int)(((unsigned)(4 * h) * (unsigned)ldo + (unsigned)r) * 4u);
+    const int row_bytes = (int)ldo * 4;
+    const unsigned span = (unsigned)(32 * RT) * (unsigned)ldo * 4u;
+    float* const s_rows = S + i0 * ldo;
+
+    // A wave whose rows and whose chunk's columns are all in range issues exactly 16*RT stores per
+    // tile, so "all but the youngest 16*RT memory operations" is exactly "the next tile has landed".
+    const bool steady = (n1 - i0 >= 32 * RT) && ((tile0 + ntiles) * 32 <= n2);
+
+    auto run = [&](auto steady_tag) {
+        constexpr bool ST = decltype(steady_tag)::value;
+        constexpr int NSIDE = ST ? NPW + 16 * RT : 0;  // DMA pieces, then stores, between the MFMAs
+        constexpr int NSLOT = 3 * KS;
+
+        auto stage_piece = [&](int it, int buf, int p) {
+            const int q = 4 * p + wave;
+            if (4 * p + 3 < PIECES || q < PIECES) {
+                const int64_t slot0 = (tile0 + it) * TILE_SLOTS + q * 64;
+                const unsigned dst = lds_base + (unsigned)(buf * BUF_SLOTS + q * 64) * 16u;
+                if constexpr (ST) {
+                    lds_dma_16_uniform(H2 + slot0, lane16, dst);
+                } else {
+                    int64_t src = slot0 + lane;
+                    if (src > h2_slots - 1) src = h2_slots - 1;  // short last tile: re-read a valid slot
+                    lds_dma_16(H2 + src, dst);
+                }
+            }
+        };
+
+        f32x16 prev[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) prev[t][e] = 0.f;
+
+#pragma unroll
+        for (int p = 0; p < NPW; ++p) stage_piece(0, 0, p);
+
+        for (int it = 0; it < ntiles; ++it) {
+            const int buf = it & 1;
+            if (ST && it > 0) {
+                if constexpr (RT == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();  // tile `it` has landed; every wave is done with the other buffer
+            asm volatile("" ::: "memory");
+            const bool more = it + 1 < ntiles;
+            if constexpr (!ST) {
+                if (more) {
+#pragma unroll
+                    for (int p = 0; p < NPW; ++p) stage_piece(it + 1, buf ^ 1, p);
+                }
+            }
+            // block of the previous tile; no records for the first tile, so its stores are dropped
+            __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                s_rows + (tile0 + it - 1) * 32, 0, it > 0 ? span : 0u, 0x00020000);
+
+            f32x16 hi[RT], mid[RT], lo[RT];
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) hi[t][e] = mid[t][e] = lo[t][e] = 0.f;
+
+            const uint4* bt = tile + buf * BUF_SLOTS + r * ROW_SLOTS + h;
+            bf16x8 b0 = __builtin_bit_cast(bf16x8, bt[0]);
+            bf16x8 b1 = __builtin_bit_cast(bf16x8, bt[2]);
+            bf16x8 b2 = __builtin_bit_cast(bf16x8, bt[4]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int kn = ks + 1 < KS ? ks + 1 : ks;  // prefetch the next k-step
+                bf16x8 nb[3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    nb[g] = __builtin_bit_cast(bf16x8, bt[(3 * kn + g) * 2]);
+#pragma unroll
+                    for (int t = 0; t < RT; ++t) {
+                        if (g == 0) {
+                            mid[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1][ks], b0, mid[t], 0, 0, 0);
+                            lo[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][2][ks], b0, lo[t], 0, 0, 0);
+                        } else if (g == 1) {
+                            hi[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0][ks], b0, hi[t], 0, 0, 0);
+                            lo[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1][ks], b1, lo[t], 0, 0, 0);
+                        } else {
+                            mid[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0][ks], b1, mid[t], 0, 0, 0);
+                            lo[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0][ks], b2, lo[t], 0, 0, 0);
+                        }
+                    }
+                    // side work of this slot
+                    const int j = 3 * ks + g;
+#pragma unroll
+                    for (int idx = j * NSIDE / NSLOT; idx < (j + 1) * NSIDE / NSLOT; ++idx) {
+                        if (idx < NPW) {
+                            if (more) stage_piece(it + 1, buf ^ 1, idx);
+                        } else {
+                            const int e = (idx - NPW) & 15, t = (idx - NPW) >> 4;
+                            const int rr = 32 * t + (e & 3) + 8 * (e >> 2);
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[t][e]), rsrc, vb,
+                                                                  rr * row_bytes, 2);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                b0 = nb[0], b1 = nb[1], b2 = nb[2];
+            }
+#pragma unroll
+            for (int t = 0; t < RT; ++t) prev[t] = hi[t] + (mid[t] + lo[t]);
+
+            if constexpr (!ST) {
+                const int64_t col0 = (tile0 + it) * 32;
+                const int64_t rows_left = n1 - i0;  // wave-uniform
+                if (col0 + r < n2) {
+#pragma unroll
+                    for (int t = 0; t < RT; ++t)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int rr = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+                            if (rr < rows_left)
+                                __builtin_nontemporal_store(prev[t][e], s_rows + rr * ldo + col0 + r);
+                        }
+                }
+            }
+        }
+        if constexpr (ST) {  // scores of the last tile
+            __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                s_rows + (tile0 + ntiles - 1) * 32, 0, span, 0x00020000);
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rr = 32 * t + (e & 3) + 8 * (e >> 2);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[t][e]), rsrc, vb,
+                                                          rr * row_bytes, 2);
+                }
+        }
+    };
+    if (steady) run(std::true_type{});
+    else run(std::false_type{});
+#endif
+}
+
+#define HYPMI_DEFINE_SPLIT_LAUNCH(KS, RT)                                                         \
+    static int launch_split_##KS(const uint4* H1, int64_t n1, const uint4* H2, int64_t n2, float* S,   \
+                                 int64_t lds, hipStream_t stream) {                                    \
+        LaunchGeom g;                                                                                  \
+        int rc = launch_geometry(n1, n2, 128 * RT, &g);                                                \
+        if (rc != HYPMI_OK) return rc;                                                                 \
+        hipLaunchKernelGGL((score_split_kernel<KS, RT>), dim3((unsigned)g.gx, (unsigned)g.gy),         \
+                           dim3(256), 0, stream, H1, H2, S, n1, n2, lds, g.tiles_per_chunk);           \
+        HYPMI_HIP(hipGetLastError());                                                                  \
+        return HYPMI_OK;                                                                               \
+    }
+
+HYPMI_DEFINE_SPLIT_LAUNCH(1, 1)
+HYPMI_DEFINE_SPLIT_LAUNCH(2, 1)
+HYPMI_DEFINE_SPLIT_LAUNCH(4, 1)
+HYPMI_DEFINE_SPLIT_LAUNCH(6, 1)
+HYPMI_DEFINE_SPLIT_LAUNCH(8, 1)
+HYPMI_DEFINE_SPLIT_LAUNCH(10, 1)
+#undef HYPMI_DEFINE_SPLIT_LAUNCH
+
+}  // namespace hypmi_detail
+
+using namespace hypmi_detail;
+
+// k-steps of the split kernel for a packed width, 0 if there is no instantiation for it
+static int split_ksteps(int kp) {
+    if (kp <= 0 || kp % 8 != 0) return 0;
+    static const int ks_list[] = {1, 2, 4, 6, 8, 10};
+    const int need = (kp + 15) / 16;
+    for (int ks : ks_list)
+        if (ks >= need) return ks;
+    return 0;
+}
+
+extern "C" int64_t hypmi_split_row_bytes(int kp) {
+    const int ks = split_ksteps(kp);
+    return ks ? (int64_t)(6 * ks + 1) * 16 : 0;
+}
+
+// n rows plus 1 KiB: the last LDS-DMA piece of a tile copies up to 63 slots beyond it
+extern "C" int64_t hypmi_split_bytes(int kp, int64_t n) {
+    const int64_t rb = hypmi_split_row_bytes(kp);
+    return (rb && n >= 0) ? n * rb + 1024 : 0;
+}
+
+extern "C" int hypmi_split_rows(const float* G, int64_t n, int kp, void* H, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int ks = split_ksteps(kp);
+    HYPMI_REQUIRE(ks > 0, "split_rows: no split kernel for packed width %d", kp);
+    HYPMI_REQUIRE(n >= 0, "split_rows: bad row count");
+    if (n == 0) return HYPMI_OK;
+    HYPMI_REQUIRE(G && H, "split_rows: null pointer");
+    HYPMI_REQUIRE(aligned16(G) && aligned16(H), "split_rows: buffers must be 16-byte aligned");
+    const int64_t threads = n * 2 * ks;
+    const int64_t blocks = (threads + 255) / 256;
+    HYPMI_REQUIRE(blocks <= 0x7fffffffLL, "split_rows: too many rows");
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, G, n, kp, ks,
+                       static_cast<uint4*>(H));
+    HYPMI_HIP(hipGetLastError());
+    return HYPMI_OK;
+}
+
+extern "C" int hypmi_score_split(const void* H1_, int64_t n1, const void* H2_, int64_t n2, int kp,
+                                 float* S, int64_t lds, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int ks = split_ksteps(kp);
+    HYPMI_REQUIRE(ks > 0, "score_split: no split kernel for packed width %d", kp);
+    HYPMI_REQUIRE(n1 >= 0 && n2 >= 0, "score_split: bad shape n1=%lld n2=%lld", (long long)n1,
+                  (long long)n2);
+    HYPMI_REQUIRE(lds >= n2, "score_split: output leading dimension %lld < n2 %lld", (long long)lds,
+                  (long long)n2);
+    if (n1 == 0 || n2 == 0) return HYPMI_OK;
+    HYPMI_REQUIRE(H1_ && H2_ && S, "score_split: null pointer");
+    HYPMI_REQUIRE(aligned16(H1_) && aligned16(H2_), "score_split: split rows must be 16-byte aligned");
+    const uint4* H1 = static_cast<const uint4*>(H1_);
+    const uint4* H2 = static_cast<const uint4*>(H2_);
+    switch (ks) {
+        case 1: return launch_split_1(H1, n1, H2, n2, S, lds, stream);
+        case 2: return launch_split_2(H1, n1, H2, n2, S, lds, stream);
+        case 4: return launch_split_4(H1, n1, H2, n2, S, lds, stream);
+        case 6: return launch_split_6(H1, n1, H2, n2, S, lds, stream);
+        case 8: return launch_split_8(H1, n1, H2, n2, S, lds, stream);
+        default: return launch_split_10(H1, n1, H2, n2, S, lds, stream);
+    }
+}

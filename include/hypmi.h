@@ -107,6 +107,21 @@ int hypmi_transform(const hypmi_plan* plan, const float* x, int64_t n, int64_t l
 int hypmi_score(const float* G1, int64_t n1, const float* G2, int64_t n2, int kp, float* S,
                 int64_t lds, void* stream);
 
+/* The same score matrix (same reference lines as hypmi_score) from split rows, on the bf16 matrix
+ * cores: each fp32 of a packed row is stored as the exact sum of three bf16 numbers and the six
+ * largest of the nine partial products are accumulated in fp32, which keeps the accuracy of an
+ * fp32 product chain at 2.7 times its arithmetic rate.
+ * hypmi_split_row_bytes: bytes of one split row for packed width kp, 0 when kp has no split kernel
+ * (then hypmi_score is the only path).  hypmi_split_bytes: size of a buffer of n split rows (the
+ * rows plus 1 KiB that the kernel may read but never uses).  hypmi_split_rows: G [n x kp] -> H;
+ * either side's packed rows may be converted, the format is the same.  hypmi_score_split: S as
+ * above, H1 / H2 in buffers of at least hypmi_split_bytes. */
+int64_t hypmi_split_row_bytes(int kp);
+int64_t hypmi_split_bytes(int kp, int64_t n);
+int hypmi_split_rows(const float* G, int64_t n, int kp, void* H, void* stream);
+int hypmi_score_split(const void* H1, int64_t n1, const void* H2, int64_t n2, int kp, float* S,
+                      int64_t lds, void* stream);
+
 /* Generic y = x Wt^T + bias (one np.dot(x - mu, T) of the reference, with -mu T in bias).
  * Wt is [d_out x ldw] (the transposed weight, rows padded with zeros to ldw). */
 int hypmi_affine(const float* x, int64_t n, int64_t ldx, int d_in, const float* Wt, int64_t ldw,

@@ -438,3 +438,97 @@ def test_topk_boundary_redecided_from_packed_rows():
     assert bad_plain > 10, bad_plain      # the test bites: fp32 alone picks wrong members
     assert bad_exact == 0, (bad_exact, exact["counters"])
     assert exact["counters"][0] > 0 and exact["counters"][1] == 0
+
+
+def _decode_split(H, n, kp):
+    """Split rows (int32 words) -> float64 [3, n, 16 * ks] of the three bf16 parts."""
+    row_words = H.numel() and (H.shape[0] - 256) // max(n, 1)
+    rows = H[:n * row_words].cpu().numpy().view(np.uint32).reshape(n, row_words // 4, 4)
+    ks = (row_words // 4 - 1) // 6
+    out = np.zeros((3, n, 16 * ks), dtype=np.float64)
+    for k16 in range(ks):
+        for s in range(3):
+            for h in range(2):
+                w = rows[:, (3 * k16 + s) * 2 + h, :]                       # 4 words = 8 bf16
+                bits = np.stack([w & 0xffff, w >> 16], axis=-1).reshape(n, 8)
+                vals = (bits.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+                out[s, :, 16 * k16 + 8 * h:16 * k16 + 8 * h + 8] = vals
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kp", [16, 64, 152])
+def test_split_rows_are_exact(kp):
+    """x0 + x1 + x2 reproduces every fp32 value bit for bit (the split kernel's only approximation is
+    then the three dropped partial products); non-finite values keep their class.  (Below 2^-110 the
+    low parts fall into the bf16 subnormals and lose bits; packed rows never hold such values.)"""
+    import torch
+
+    from hyperion_amd import engine
+
+    rng = np.random.RandomState(kp)
+    n = 300
+    x = (rng.randn(n, kp) * np.exp(rng.uniform(-30, 30, size=(n, kp)))).astype(np.float32)
+    x[0, :8] = [0.0, -0.0, 1.0, -1.0, 3.3895314e38, -3.4028235e38, 1e-30, -2.5e-31]
+    G = torch.from_numpy(x).cuda()
+    H = engine.split_rows(G)
+    parts = _decode_split(H.H, n, kp)
+    back = parts.sum(axis=0)[:, :kp].astype(np.float32)
+    bad = np.argwhere(back != x)
+    assert bad.size == 0, "first mismatches: %s" % [(tuple(i), x[tuple(i)], back[tuple(i)]) for i in bad[:5]]
+    assert np.all(parts[:, :, kp:] == 0)
+    # magnitudes fall by 2^-8 per part (round to nearest: half an 8-bit ulp; one bit of slack for
+    # the largest fp32, whose leading part is kept finite by rounding down)
+    assert np.all(np.abs(parts[1]) <= np.abs(parts[0]) * 2.0 ** -7)
+    assert np.all(np.abs(parts[2]) <= np.abs(parts[0]) * 2.0 ** -15)
+    y = np.ones((4, kp), dtype=np.float32)
+    y[1, 3] = np.inf
+    y[2, 5] = np.nan
+    y[3, 0] = -np.inf
+    p = _decode_split(engine.split_rows(torch.from_numpy(y).cuda()).H, 4, kp)
+    assert np.isposinf(p[0, 1, 3]) and np.isnan(p[0, 2, 5]) and np.isneginf(p[0, 3, 0])
+    assert np.all(p[1:] == 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kp", [16, 32, 64, 96, 128, 152])
+@pytest.mark.parametrize("n1,n2", [(1, 1), (31, 33), (128, 2048), (333, 2100), (700, 4133)])
+def test_split_score_matches_float64(kp, n1, n2):
+    """bf16 three-way split kernel against a float64 product of the same fp32 rows: the error stays
+    within the fp32 bound 8 * 2^-24 * sum|a b| on every entry, as does the fp32 kernel's."""
+    import torch
+
+    from hyperion_amd import engine
+
+    g = torch.Generator(device="cuda").manual_seed(kp * 7 + n1)
+    G1 = torch.randn((n1, kp), device="cuda", generator=g) * 3.0
+    G2 = torch.randn((n2, kp), device="cuda", generator=g) * 0.7
+    G1[:, kp - 2] = torch.randn(n1, device="cuda", generator=g) * 500.0
+    G1[:, kp - 1] = 1.0
+    G2[:, kp - 2] = 1.0
+    G2[:, kp - 1] = torch.randn(n2, device="cuda", generator=g) * 500.0
+    ref = (G1.double() @ G2.double().T).cpu().numpy()
+    bound = (G1.double().abs() @ G2.double().abs().T).cpu().numpy() * engine.ERR_COEFF
+    S_split = engine.score(G1, G2).cpu().numpy()
+    S_fp32 = engine.score(G1, G2, split=False).cpu().numpy()
+    assert S_split.shape == (n1, n2)
+    assert np.all(np.abs(S_split - ref) <= bound)
+    assert np.all(np.abs(S_fp32 - ref) <= bound)
+
+
+@pytest.mark.gpu
+def test_split_score_propagates_nan_rows():
+    import torch
+
+    from hyperion_amd import engine
+
+    G1 = torch.randn((70, 32), device="cuda")
+    G2 = torch.randn((90, 32), device="cuda")
+    G1[5, 3] = float("nan")
+    G2[7, 0] = float("nan")
+    S = engine.score(G1, G2).cpu().numpy()
+    assert np.all(np.isnan(S[5])) and np.all(np.isnan(S[:, 7]))
+    mask = np.ones_like(S, dtype=bool)
+    mask[5] = False
+    mask[:, 7] = False
+    assert np.all(np.isfinite(S[mask]))

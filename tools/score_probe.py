@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Time hypmi_score alone (HIP events on torch's stream) for a given shape; HYPMI_SCORE_VARIANT picks
-an experimental kernel variant when the library was built with them."""
+"""Time the two score kernels alone (HIP events on torch's stream) for a given shape and compare
+their rounding error against float64 on a slab of the matrix."""
 import argparse
 import os
 import sys
@@ -15,30 +15,59 @@ ap.add_argument("--n1", type=int, default=100000)
 ap.add_argument("--n2", type=int, default=100000)
 ap.add_argument("--kp", type=int, default=152)
 ap.add_argument("--reps", type=int, default=5)
-ap.add_argument("--variants", default="0")
+ap.add_argument("--scale", type=float, default=1.0)
 a = ap.parse_args()
 lib = _lib.load()
 g = torch.Generator(device="cuda").manual_seed(0)
-G1 = torch.randn((a.n1, a.kp), device="cuda", generator=g)
-G2 = torch.randn((a.n2, a.kp), device="cuda", generator=g)
+G1 = torch.randn((a.n1, a.kp), device="cuda", generator=g) * a.scale
+G2 = torch.randn((a.n2, a.kp), device="cuda", generator=g) * a.scale
+# columns shaped like real packed rows: a large q against a one
+G1[:, a.kp - 2] = torch.randn(a.n1, device="cuda", generator=g) * 300.0
+G1[:, a.kp - 1] = 1.0
+G2[:, a.kp - 2] = 1.0
+G2[:, a.kp - 1] = torch.randn(a.n2, device="cuda", generator=g) * 300.0
 S = torch.empty((a.n1, engine.round_up(a.n2, 32)), device="cuda")[:, :a.n2]
-ref = None
-for v in a.variants.split(","):
-    os.environ["HYPMI_SCORE_VARIANT"] = v
-    engine.score(G1, G2, out=S)
+rows = slice(0, min(a.n1, 517))
+cols = slice(max(a.n2 - 1031, 0), a.n2)
+ref = G1[rows].double() @ G2[cols].double().T
+bound = (G1[rows].double().abs() @ G2[cols].double().abs().T)
+
+
+def timed(fn):
+    fn()
     torch.cuda.synchronize()
     ts = []
     for _ in range(a.reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        engine.score(G1, G2, out=S)
+        fn()
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
-    chk = float(S[::997, ::991].double().sum())
-    if ref is None:
-        ref = chk
-    ms = min(ts)
-    tf = 2.0 * (a.kp - 2) * a.n1 * a.n2 / ms / 1e9
-    print("variant %s: min %.3f ms  median %.3f ms  -> %.1f TF (K=kp-2)  %.1f%% of 157.3  checksum %s"
-          % (v, ms, sorted(ts)[len(ts) // 2], tf, tf / 1.573, "ok" if abs(chk - ref) <= 1e-6 * abs(ref) else "DIFF %r %r" % (chk, ref)))
+    return min(ts), sorted(ts)[len(ts) // 2]
+
+
+def report(name, ms, med):
+    err = (S[rows, cols].double() - ref).abs()
+    tf = 2.0 * a.kp * a.n1 * a.n2 / ms / 1e9
+    print("%-10s min %.3f ms  median %.3f ms  %.1f fp32-equivalent TF  %.2f TB/s stored | max err %.3e  "
+          "max err/sum|ab| %.3e (fp32 unit 5.96e-8)  rms %.3e"
+          % (name, ms, med, tf, 4.0 * a.n1 * a.n2 / ms / 1e9, float(err.max()),
+             float((err / bound).max()), float(err.pow(2).mean().sqrt())))
+
+
+ms, med = timed(lambda: engine.score(G1, G2, out=S, split=False))
+report("fp32", ms, med)
+if lib.hypmi_split_row_bytes(a.kp):
+    S.zero_()
+    H1, H2 = engine.split_rows(G1), engine.split_rows(G2)
+    ms, med = timed(lambda: engine.score(H1, H2, out=S))
+    report("bf16x3", ms, med)
+    ms, med = timed(lambda: (engine.split_rows(G1), engine.split_rows(G2)))
+    print("split_rows of both sides: %.3f ms" % ms)
+    for dbg in os.environ.get("PROBE_DBG", "").split(","):
+        if dbg:
+            os.environ["HYPMI_SPLIT_DBG"] = dbg
+            ms, med = timed(lambda: engine.score(H1, H2, out=S))
+            print("dbg %s (1 = no stores, 2 = no DMA, 4 = no LDS re-reads): min %.3f ms" % (dbg, ms))
+            os.environ.pop("HYPMI_SPLIT_DBG")

@@ -1,7 +1,16 @@
 #!/usr/bin/env python
-"""Summarise a tools/profile.sh output directory into one small text file for profiles/."""
+"""Summarise a tools/profile.sh output directory into one small text file for profiles/.
+
+    summarize_prof.py <prof dir> <summary.txt> [<workload> <kernel substring> <traffic.json>]
+
+With the three optional arguments the HBM bytes per launch of the named kernel are written into
+traffic.json under the workload's key: FETCH_SIZE and WRITE_SIZE are reported in KiB; on gfx950
+FETCH_SIZE counts a 128-byte read request as 64 bytes for wide coalesced reads (16 bytes per lane,
+which is what the LDS-DMA and the stationary-row loads of the score kernels are), so it is doubled;
+WRITE_SIZE was calibrated on the score matrix itself (it reports n1 * n2 * 4 bytes exactly)."""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
@@ -12,8 +21,9 @@ def find(d, pat):
     return r[0] if r else None
 
 
-def main(d, out):
+def main(d, out, traffic=None):
     lines = []
+    means = {}
     st = find(os.path.join(d, "trace"), "*kernel_stats.csv")
     if st:
         lines.append("== rocprofv3 --kernel-trace --stats (kernel_stats.csv) ==")
@@ -36,9 +46,29 @@ def main(d, out):
         for k, cs in acc.items():
             for c, v in cs.items():
                 lines.append("%-70s %-28s n=%-4d mean=%.6g" % (k[:70], c, len(v), sum(v) / len(v)))
+                means[(k, c)] = sum(v) / len(v)
+    if traffic:
+        workload, sub, path = traffic
+        fetch = [v for (k, c), v in means.items() if sub in k and c == "FETCH_SIZE"]
+        write = [v for (k, c), v in means.items() if sub in k and c == "WRITE_SIZE"]
+        if fetch and write:
+            try:
+                with open(path) as f:
+                    db = json.load(f)
+            except (OSError, ValueError):
+                db = {}
+            db[workload] = {"kernel": sub, "fetch_bytes_corrected": fetch[0] * 1024 * 2,
+                            "write_bytes": write[0] * 1024,
+                            "hbm_bytes_per_launch": fetch[0] * 1024 * 2 + write[0] * 1024,
+                            "source": os.path.basename(out)}
+            with open(path, "w") as f:
+                json.dump(db, f, indent=1, sort_keys=True)
+            lines.append("")
+            lines.append("HBM traffic per launch of %s: fetch %.3f GB (x2 corrected), write %.3f GB"
+                         % (sub, fetch[0] * 2048 / 1e9, write[0] * 1024 / 1e9))
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3:6] if len(sys.argv) >= 6 else None)
