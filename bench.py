@@ -272,7 +272,7 @@ def main():
             "parallelism": "test rows sharded over %d GPU(s), enrol replicated" % world,
         },
         "roofline": {
-            "kernel": ("score_split_kernel<%d,1>" % ((plan.kp + 15) // 16)) if use_split
+            "kernel": ("score_split_kernel<%d>" % ((plan.kp + 31) // 32)) if use_split
                       else "score_rs_kernel<%d,2>" % plan.kp,
             "bound": "mfma",
             "achieved": achieved_tflops,

@@ -441,18 +441,26 @@ def test_topk_boundary_redecided_from_packed_rows():
 
 
 def _decode_split(H, n, kp):
-    """Split rows (int32 words) -> float64 [3, n, 16 * ks] of the three bf16 parts."""
-    row_words = H.numel() and (H.shape[0] - 256) // max(n, 1)
-    rows = H[:n * row_words].cpu().numpy().view(np.uint32).reshape(n, row_words // 4, 4)
-    ks = (row_words // 4 - 1) // 6
-    out = np.zeros((3, n, 16 * ks), dtype=np.float64)
-    for k16 in range(ks):
+    """Split rows (int32 words) -> float64 [3, n, 16 * ks16] of the three bf16 parts.  Row layout:
+    [HS slots: even 8-chunks][3 * ks16 slots: odd 8-chunks][pad], slot 3 * j + s of a half = part s
+    of chunk pair j; HS = 3 * ks16 rounded up to 16, ks16 = 2 * ceil(kp / 32)."""
+    ks16 = 2 * ((kp + 31) // 32)
+    hs = (3 * ks16 + 15) // 16 * 16
+    row_slots = (hs + 3 * ks16) | 1
+    assert H.numel() == n * row_slots * 4 + 256
+    rows = H[:n * row_slots * 4].cpu().numpy().view(np.uint32).reshape(n, row_slots, 4)
+    out = np.zeros((3, n, 16 * ks16), dtype=np.float64)
+    used = np.zeros(row_slots, dtype=bool)
+    for j in range(ks16):
         for s in range(3):
             for h in range(2):
-                w = rows[:, (3 * k16 + s) * 2 + h, :]                       # 4 words = 8 bf16
+                slot = h * hs + 3 * j + s
+                used[slot] = True
+                w = rows[:, slot, :]                                        # 4 words = 8 bf16
                 bits = np.stack([w & 0xffff, w >> 16], axis=-1).reshape(n, 8)
                 vals = (bits.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
-                out[s, :, 16 * k16 + 8 * h:16 * k16 + 8 * h + 8] = vals
+                out[s, :, 16 * j + 8 * h:16 * j + 8 * h + 8] = vals
+    assert np.all(rows[:, ~used, :] == 0)                                   # padding slots are cleared
     return out
 
 
