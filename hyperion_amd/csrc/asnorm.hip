@@ -284,6 +284,408 @@ __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float* __re
     }
 }
 
+// ---- register-resident top-k (cohorts up to 40 960) ---------------------------------------------
+// One workgroup of 256 threads per row; thread t keeps the keys of cohort members t, t + 256, ... in
+// ITEMS registers (no LDS copy of the row, no atomics on it).  The key at descending rank `want` is
+// found bit by bit from the top: the answer has bit b set iff more than `want` keys are
+// >= (prefix | 1 << b).  One step is ITEMS compares per thread, a ballot count per wave and one
+// barrier.  As soon as at most 1024 keys are left inside the bracket [prefix, prefix + 2^b) they are
+// copied into four registers per thread and the remaining steps cost four compares.  Four such
+// workgroups share a CU, so the barriers of one overlap the compares of the others.
+constexpr int TR_THREADS = 256, TR_WAVES = TR_THREADS / 64;
+constexpr int TR_CAND = 1024;     // the bracket is narrow once it holds at most this many keys
+constexpr int TR_STAGE = 8192;    // longest list staged in LDS before it is written (entries)
+constexpr int TR_MAX_ITEMS = 160;
+constexpr int TR_MAX_NC = TR_MAX_ITEMS * TR_THREADS;
+
+struct TopkShared {
+    unsigned cnt[2][TR_WAVES];             // per-wave counters, alternating between steps
+    unsigned ncand;                        // candidates written so far / boundary candidates
+    unsigned cand[TR_CAND]; // keys inside the bracket
+};
+
+// Sum over the workgroup of a per-wave count (one barrier; the counter slots alternate so that the
+// next call may start before every wave has read this one).
+__device__ __forceinline__ int block_sum(TopkShared& sh, int& par, unsigned wave_count, int lane, int wave) {
+    // The count is pinned in a scalar register here: sunk into the lane-0 branch below, its popcounts
+    // would keep every ballot mask of the caller alive across that branch.
+    asm volatile("" : "+s"(wave_count));
+    if (lane == 0) sh.cnt[par][wave] = wave_count;
+    __syncthreads();
+    const uint4 v = *reinterpret_cast<const uint4*>(sh.cnt[par]);
+    par ^= 1;
+    return (int)(v.x + v.y + v.z + v.w);
+}
+
+// Makes the compiler forget what it knows about x (no instruction): keeps it from carrying dozens of
+// 64-bit ballot masks across a barrier instead of recomputing them from one register.
+__device__ __forceinline__ void opaque(unsigned& x) { asm volatile("" : "+v"(x)); }
+
+// Population counts of four ballot masks, issued where they stand: left to the compiler, the counts
+// of an unrolled loop are all moved behind the compares and every mask has to be kept (and spilled);
+// one at a time, every compare waits for the previous count to free the mask register.
+__device__ __forceinline__ unsigned mask_count4(unsigned long long m0, unsigned long long m1,
+                                                unsigned long long m2, unsigned long long m3) {
+    unsigned c0, c1, c2, c3;
+    asm volatile(
+        "s_bcnt1_i32_b64 %0, %4\n\ts_bcnt1_i32_b64 %1, %5\n\ts_bcnt1_i32_b64 %2, %6\n\ts_bcnt1_i32_b64 %3, %7"
+        : "=&s"(c0), "=&s"(c1), "=&s"(c2), "=&s"(c3)
+        : "s"(m0), "s"(m1), "s"(m2), "s"(m3)
+        : "scc");
+    return (c0 + c1) + (c2 + c3);
+}
+__device__ __forceinline__ unsigned mask_count(unsigned long long m) {
+    unsigned c;
+    asm volatile("s_bcnt1_i32_b64 %0, %1" : "=s"(c) : "s"(m) : "scc");
+    return c;
+}
+
+// number of set bits of m below this lane
+__device__ __forceinline__ unsigned lanes_below(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+template <int ITEMS>
+struct TopkRegs {
+    unsigned key[ITEMS];
+
+    template <class P>
+    __device__ __forceinline__ unsigned wave_count(P pred) const {
+        unsigned c = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; j += 4)
+            c += mask_count4(__ballot(pred(key[j])), __ballot(pred(key[j + 1])), __ballot(pred(key[j + 2])),
+                             __ballot(pred(key[j + 3])));
+        return c;
+    }
+
+    // Key T at descending rank `want` (0-based), the number of keys > T and the number == T.
+    __device__ __forceinline__ void select(int want, int nc, TopkShared& sh, int& par, int tid, unsigned* out_key,
+                                           int* out_gt, int* out_eq) {
+        const int lane = tid & 63, wave = tid >> 6;
+        unsigned prefix = 0;
+        int c_lo = nc;  // keys >= prefix
+        int c_hi = 0;   // keys >= prefix + 2^(b+1): above the bracket
+        int b = 31;
+        for (; b >= 0; --b) {
+            if (c_lo - c_hi <= TR_CAND && b < 31) break;
+            const unsigned cand = prefix | (1u << b);
+            const int c = block_sum(sh, par, wave_count([cand](unsigned kx) { return kx >= cand; }), lane, wave);
+            if (c > want) {
+                prefix = cand;
+                c_lo = c;
+            } else {
+                c_hi = c;
+            }
+        }
+        if (b >= 0) {
+            // bracket [prefix, prefix + 2^(b+1)) holds c_lo - c_hi <= 1024 keys: move them to registers
+            const unsigned width = b == 31 ? 0u : (1u << (b + 1));  // b < 31 here
+            if (tid == 0) sh.ncand = 0;
+            __syncthreads();
+            auto inside = [prefix, width](unsigned kx) { return kx != 0 && kx - prefix < width; };  // key 0 = no element
+            const unsigned mine = wave_count(inside);
+            unsigned at = 0;
+            if (lane == 0) at = atomicAdd(&sh.ncand, mine);  // one slot range per wave
+            at = __shfl(at, 0, 64);
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) opaque(key[j]);  // recompute the ballots rather than keep ITEMS masks
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const bool in = inside(key[j]);
+                const unsigned long long m = __ballot(in);
+                if (in) sh.cand[at + lanes_below(m)] = key[j];
+                at += mask_count(m);
+            }
+            __syncthreads();
+            // Every wave now takes ALL candidates (TR_CAND / 64 per lane) and finishes the remaining
+            // bits on its own: same data, same result in every wave, no barrier and no LDS per step.
+            const int n_in = c_lo - c_hi;
+            unsigned ck[TR_CAND / 64];
+#pragma unroll
+            for (int u = 0; u < TR_CAND / 64; ++u) {
+                const int e = u * 64 + lane;
+                ck[u] = e < n_in ? sh.cand[e] : 0u;  // key 0 never counts (candidates are >= 1)
+            }
+            const int above = c_hi;  // keys above the bracket as it was when the candidates were copied
+            for (; b >= 0; --b) {
+                const unsigned cand = prefix | (1u << b);
+                unsigned wc = 0;
+#pragma unroll
+                for (int u = 0; u < TR_CAND / 64; u += 4)
+                    wc += mask_count4(__ballot(ck[u] >= cand), __ballot(ck[u + 1] >= cand),
+                                      __ballot(ck[u + 2] >= cand), __ballot(ck[u + 3] >= cand));
+                const int c = above + (int)wc;
+                if (c > want) {
+                    prefix = cand;
+                    c_lo = c;
+                } else {
+                    c_hi = c;
+                }
+            }
+        }
+        *out_key = prefix;
+        *out_gt = c_hi;          // keys >= prefix + 1
+        *out_eq = c_lo - c_hi;   // keys == prefix
+    }
+};
+
+template <int ITEMS>
+__global__ __launch_bounds__(TR_THREADS) void topk_rows_reg_kernel(const float* __restrict__ A, int64_t lda,
+                                                                   int nc, int k, int discard,
+                                                                   uint16_t* __restrict__ idx8, int64_t ldi,
+                                                                   ExactSrc ex) {
+    __shared__ __attribute__((aligned(16))) TopkShared sh;
+    __shared__ unsigned tab[TR_WAVES * ((ITEMS + 63) / 64) * 64];  // per (wave, item) counts for the ordered compaction
+    __shared__ double exact_s[TK_CAND];
+    __shared__ unsigned short cand_idx[2 * TK_CAND];
+    __shared__ unsigned char cand_above[2 * TK_CAND];
+    __shared__ __attribute__((aligned(16))) unsigned short stage[TR_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = blockIdx.x;
+    int par = 0;
+    TopkRegs<ITEMS> R;
+    const float* src = A + row * lda;
+    // All loads of the row are issued before the first use (clamped index, no branch per item).
+    // Key 0 is reserved for "no element": real keys are at least 1 (only the all-ones NaN maps lower).
+    {
+        float raw[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int i = j * TR_THREADS + tid;
+            raw[j] = __builtin_nontemporal_load(src + (i < nc ? i : nc - 1));
+        }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const unsigned kx = key_of(raw[j]);
+            R.key[j] = j * TR_THREADS + tid < nc ? (kx == 0 ? 1u : kx) : 0u;
+        }
+    }
+
+    const int last = discard + k;
+    const bool use_lo = discard > 0;
+    unsigned key_hi, key_lo = 0xffffffffu;
+    int gt_hi, eq_hi, gt_lo = 0, eq_lo = 0;
+    R.select(last - 1, nc, sh, par, tid, &key_hi, &gt_hi, &eq_hi);
+    if (use_lo) R.select(discard - 1, nc, sh, par, tid, &key_lo, &gt_lo, &eq_lo);
+
+    // what fp32 cannot resolve around a boundary value: re-decide those entries from float64 values
+    int n_hi = 0, n_lo = 0;
+    float thr_hi = 0.f, thr_lo = 0.f, d_hi = 0.f, d_lo = 0.f;
+    if (ex.mode != 0) {
+        thr_hi = float_of_key(key_hi);
+        thr_lo = float_of_key(key_lo);
+        if (ex.mode == 1) {  // the fp32 matrix is the rounding of the fp64 one
+            d_hi = fabsf(thr_hi) * 2.4e-7f;
+            d_lo = fabsf(thr_lo) * 2.4e-7f;
+        } else {
+            const float bound = ex.err_coeff * (ex.bnd_rows[2 * row] * ex.coh_gmax + ex.bnd_rows[2 * row + 1] +
+                                                ex.coh_qmax);
+            d_hi = d_lo = 2.f * bound;
+        }
+        // Entries above thr + delta are certainly above the boundary "rank < Rk"; m = Rk - (their
+        // count) of the candidates within +-delta must be above, chosen by exact value (ties by index).
+        auto redecide = [&](int Rk, float thr, float delta, unsigned short* cidx, unsigned char* cabove) -> int {
+            if (tid == 0) sh.ncand = 0;
+            const float hi = thr + delta, lo = thr - delta;
+            __syncthreads();  // ncand is cleared before anyone appends
+            unsigned wc = 0;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) opaque(R.key[j]);  // nothing of this pass is worth keeping
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const unsigned kx = R.key[j];
+                const float v = float_of_key(kx);
+                const bool above = kx != 0 && v > hi;
+                wc += mask_count(__ballot(above));
+                if (kx != 0 && !above && v >= lo) {
+                    const unsigned pos = atomicAdd(&sh.ncand, 1u);
+                    if (pos < TK_CAND) cidx[pos] = (unsigned short)(j * TR_THREADS + tid);
+                }
+                if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+            const int n_above = block_sum(sh, par, wc, lane, wave);
+            __syncthreads();
+            const int n_cand = (int)sh.ncand;
+            const int m = Rk - n_above;
+            if (n_cand > TK_CAND) {
+                if (tid == 0 && ex.counters) atomicAdd(&ex.counters[1], 1ull);
+                return 0;
+            }
+            if (m <= 0 || m >= n_cand) return 0;  // all candidates on one side: nothing to decide
+            if (ex.mode == 1) {
+                if (tid < n_cand) exact_s[tid] = ex.A64[row * ex.lda64 + cidx[tid]];
+            } else {
+                const int grp = tid >> 4, sub = tid & 15;
+                const double* gr = ex.G_rows + row * ex.ldg;
+                for (int a2 = grp; a2 < n_cand; a2 += TR_THREADS / 16) {
+                    const double* gc = ex.G_coh + (int64_t)cidx[a2] * ex.ldg;
+                    double acc = 0.0;
+                    for (int kk = sub; kk < ex.K; kk += 16) acc = fma(gr[kk], gc[kk], acc);
+#pragma unroll
+                    for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
+                    if (sub == 0) exact_s[a2] = acc + gr[ex.K] + gc[ex.K];
+                }
+            }
+            __syncthreads();
+            if (tid < n_cand) {
+                const double v = exact_s[tid];
+                const unsigned short me = cidx[tid];
+                int rank = 0;
+                for (int b2 = 0; b2 < n_cand; ++b2) {
+                    const double w = exact_s[b2];
+                    rank += (w > v || (w == v && cidx[b2] < me)) ? 1 : 0;
+                }
+                cabove[tid] = rank < m ? 1 : 0;
+            }
+            __syncthreads();
+            if (tid == 0 && ex.counters) atomicAdd(&ex.counters[0], 1ull);
+            return n_cand;
+        };
+        n_hi = redecide(last, thr_hi, d_hi, cand_idx, cand_above);
+        if (use_lo) n_lo = redecide(discard, thr_lo, d_lo, cand_idx + TK_CAND, cand_above + TK_CAND);
+    }
+
+    // Ordered positions.  Index order is item-major (i = j * 256 + tid), so the number of flagged
+    // entries before entry (j, wave, lane) is base(j, wave) + (flagged lower lanes of the ballot), with
+    // base(j, wave) = flagged entries of earlier (item, wave) pairs.  A wave counts its ITEMS ballots
+    // into the lanes of NW registers (v_writelane), the four waves exchange them through LDS once,
+    // and every wave scans the totals itself; base(j, wave) is then read back lane j (v_readlane).
+    constexpr int NW = (ITEMS + 63) / 64, IP = NW * 64;
+    constexpr int SELW = (ITEMS + 31) / 32;
+    auto ordered_bases = [&](const unsigned (&bits)[SELW], unsigned (&basev)[NW]) {
+        unsigned cntv[NW];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) cntv[q] = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const unsigned c = mask_count(__ballot((bits[j >> 5] >> (j & 31)) & 1u));
+            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(cntv[j >> 6]) : "s"(c), "i"(j & 63));
+        }
+        __syncthreads();  // earlier readers of tab are done
+#pragma unroll
+        for (int q = 0; q < NW; ++q) tab[wave * IP + 64 * q + lane] = cntv[q];
+        __syncthreads();
+        unsigned carry = 0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            unsigned tot = 0, mine_before = 0;
+#pragma unroll
+            for (int w = 0; w < TR_WAVES; ++w) {
+                const unsigned v = tab[w * IP + 64 * q + lane];
+                tot += v;
+                if (w < wave) mine_before += v;
+            }
+            unsigned incl = tot;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned v = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += v;
+            }
+            basev[q] = carry + incl - tot + mine_before;
+            carry += __shfl(incl, 63, 64);
+        }
+    };
+    auto base_of = [](const unsigned (&basev)[NW], int j) -> unsigned {
+        return __builtin_amdgcn_readlane(basev[j >> 6], j & 63);
+    };
+
+    // Which entries equal to a boundary key are above it: the first (wanted rank - #greater) of them in
+    // index order.  When every tie is above (the usual case: one such entry) no order is needed.
+    const int need_hi = last - gt_hi, need_lo = discard - gt_lo;  // ties to accept at each boundary
+    const bool order_hi = need_hi < eq_hi, order_lo = use_lo && need_lo < eq_lo;
+    unsigned hi_in[SELW], lo_in[SELW];  // bit j: a tie of item j would be above the boundary
+#pragma unroll
+    for (int w = 0; w < SELW; ++w) hi_in[w] = lo_in[w] = 0xffffffffu;
+    auto tie_order = [&](unsigned key_b, int need, unsigned (&bits)[SELW]) {
+        unsigned eq[SELW], basev[NW];
+#pragma unroll
+        for (int w = 0; w < SELW; ++w) eq[w] = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+            if (R.key[j] == key_b) eq[j >> 5] |= 1u << (j & 31);
+        ordered_bases(eq, basev);
+#pragma unroll
+        for (int w = 0; w < SELW; ++w) opaque(eq[w]);  // recompute the ballots rather than keep ITEMS masks
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const unsigned long long m = __ballot((eq[j >> 5] >> (j & 31)) & 1u);
+            const int before = (int)(base_of(basev, j) + lanes_below(m));
+            if (!(before < need)) bits[j >> 5] &= ~(1u << (j & 31));
+        }
+    };
+    if (order_hi) tie_order(key_hi, need_hi, hi_in);
+    if (order_lo) tie_order(key_lo, need_lo, lo_in);
+
+    // bit j of above_hi / above_lo: item j is above the boundary "rank < last" / "rank < discard"
+    unsigned above_hi[SELW], above_lo[SELW], valid[SELW];
+#pragma unroll
+    for (int w = 0; w < SELW; ++w) above_hi[w] = above_lo[w] = valid[w] = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) opaque(R.key[j]);
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const unsigned kx = R.key[j];
+        const unsigned bit = 1u << (j & 31);
+        if (kx > key_hi || (kx == key_hi && (hi_in[j >> 5] & bit))) above_hi[j >> 5] |= bit;
+        if (use_lo && (kx > key_lo || (kx == key_lo && (lo_in[j >> 5] & bit)))) above_lo[j >> 5] |= bit;
+        if (kx != 0) valid[j >> 5] |= bit;
+    }
+    // re-decided boundary candidates override the fp32 decision of their owner (item i / 256 of thread i % 256)
+    auto override_bits = [&](int n, const unsigned short* cidx, const unsigned char* cabove, unsigned (&bits)[SELW]) {
+        for (int a2 = 0; a2 < n; ++a2) {
+            const int i = cidx[a2];
+            if ((i & (TR_THREADS - 1)) == tid) {
+                const int j = i / TR_THREADS;
+                const unsigned bit = 1u << (j & 31);
+#pragma unroll
+                for (int w = 0; w < SELW; ++w)
+                    if (w == (j >> 5)) bits[w] = cabove[a2] ? (bits[w] | bit) : (bits[w] & ~bit);
+            }
+        }
+    };
+    if (n_hi) override_bits(n_hi, cand_idx, cand_above, above_hi);
+    if (n_lo) override_bits(n_lo, cand_idx + TK_CAND, cand_above + TK_CAND, above_lo);
+    unsigned selbits[SELW], basev[NW];
+#pragma unroll
+    for (int w = 0; w < SELW; ++w) selbits[w] = above_hi[w] & ~above_lo[w] & valid[w];
+    ordered_bases(selbits, basev);
+#pragma unroll
+    for (int w = 0; w < SELW; ++w) opaque(selbits[w]);  // recompute the ballots rather than keep ITEMS masks
+
+    // The list goes through LDS so that it leaves as 16-byte groups (one store per eight entries)
+    // instead of k scattered 2-byte stores; lists longer than the staging buffer are written directly.
+    const bool staged = k <= TR_STAGE;
+    const int groups = (k + 7) >> 3;
+    if (tid < 8) {
+        if (staged) stage[8 * (groups - 1) + tid] = 0;  // tail of the last group
+        else if (k + tid < 8 * groups) idx8[((int64_t)(groups - 1) * ldi + row) * 8 + ((k + tid) & 7)] = 0;
+    }
+    if (staged) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const bool sel = (selbits[j >> 5] >> (j & 31)) & 1u;
+        const unsigned long long m_sel = __ballot(sel);
+        const int pos = (int)(base_of(basev, j) + lanes_below(m_sel));
+        if (sel && pos < k) {
+            if (staged) stage[pos] = (unsigned short)(j * TR_THREADS + tid);
+            else idx8[((int64_t)(pos >> 3) * ldi + row) * 8 + (pos & 7)] = (uint16_t)(j * TR_THREADS + tid);
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        for (int g = tid; g < groups; g += TR_THREADS)
+            reinterpret_cast<uint4*>(idx8)[(int64_t)g * ldi + row] = reinterpret_cast<const uint4*>(stage)[g];
+    }
+}
+
+template <int ITEMS>
+void launch_topk_reg(const float* A, int64_t n_rows, int nc, int64_t lda, int k, int discard, uint16_t* idx_t,
+                     int64_t ldi, const ExactSrc& ex, hipStream_t stream) {
+    hipLaunchKernelGGL((topk_rows_reg_kernel<ITEMS>), dim3((unsigned)n_rows), dim3(TR_THREADS), 0, stream, A,
+                       lda, nc, k, discard, idx_t, ldi, ex);
+}
+
 // R rows of X per workgroup, held in LDS interleaved (xr[c * R + rr]); lanes over lists q.
 //   mean[r, q] = sum_j X[r, L[j, q]] / norm,  istd[r, q] = 1 / max(sqrt(sum x^2 / norm - mean^2), floor)
 // Without a mask the moments are accumulated in fp32 around a per-(row, list) pivot (the list's first
@@ -549,8 +951,7 @@ constexpr int MAX_LDS_BYTES = 160 * 1024;
 }  // namespace
 
 extern "C" int64_t hypmi_topk_workspace_bytes(int64_t n_rows, int nc) {
-    const int64_t lds_need = (368 + (int64_t)nc) * 4;
-    return lds_need <= MAX_LDS_BYTES ? 0 : n_rows * (int64_t)nc * 4;
+    return nc <= TR_MAX_NC ? 0 : n_rows * (int64_t)nc * 4;
 }
 
 extern "C" int64_t hypmi_topk_list_bytes(int k, int64_t ldi) {
@@ -593,14 +994,15 @@ extern "C" int hypmi_topk_rows(const float* A, int64_t n_rows, int nc, int64_t l
         ex.counters = exact->counters;
     }
     if (n_rows == 0) return HYPMI_OK;
-    const int64_t lds_need = (368 + (int64_t)nc) * 4;
-    if (lds_need <= MAX_LDS_BYTES) {
-        if (lds_need > 48 * 1024)
-            HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_rows_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
-        hipLaunchKernelGGL(topk_rows_kernel<true>, dim3((unsigned)n_rows), dim3(TK_THREADS), lds_need,
-                           stream, A, lda, nc, k, discard, idx_t, ldi, (unsigned*)nullptr, ex);
-    } else {
+    if (nc <= TR_MAX_NC) {  // keys in registers
+        const int items = (nc + TR_THREADS - 1) / TR_THREADS;
+#define HYPMI_TOPK_CASE(N) \
+    if (items <= N) { launch_topk_reg<N>(A, n_rows, nc, lda, k, discard, idx_t, ldi, ex, stream); } else
+        HYPMI_TOPK_CASE(4) HYPMI_TOPK_CASE(8) HYPMI_TOPK_CASE(16) HYPMI_TOPK_CASE(32) HYPMI_TOPK_CASE(48)
+        HYPMI_TOPK_CASE(64) HYPMI_TOPK_CASE(80) HYPMI_TOPK_CASE(96) HYPMI_TOPK_CASE(128)
+        { launch_topk_reg<TR_MAX_ITEMS>(A, n_rows, nc, lda, k, discard, idx_t, ldi, ex, stream); }
+#undef HYPMI_TOPK_CASE
+    } else {  // keys in a global workspace, radix select with LDS histograms
         HYPMI_REQUIRE(workspace && workspace_bytes >= n_rows * (int64_t)nc * 4,
                       "topk_rows: cohort of %d needs a %lld-byte workspace", nc,
                       (long long)(n_rows * (int64_t)nc * 4));

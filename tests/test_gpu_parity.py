@@ -540,3 +540,25 @@ def test_split_score_propagates_nan_rows():
     mask[5] = False
     mask[:, 7] = False
     assert np.all(np.isfinite(S[mask]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,nc,k,disc,shift", [
+    (7, 50, 10, 0, 0.0), (7, 50, 10, 0, -100.0), (5, 50, 10, 3, 0.0), (9, 700, 33, 0, 0.0),
+    (4, 1500, 100, 5, 0.0), (6, 5000, 300, 0, 0.0), (3, 20000, 300, 0, 0.0), (3, 20000, 300, 7, -3.0),
+    (2, 40960, 1000, 0, 0.0), (3, 300, 300, 0, 0.0), (2, 45000, 64, 2, 1.0)])
+def test_topk_rows_matches_stable_argsort(n, nc, k, disc, shift):
+    """Every size class of the register-resident top-k (and the workspace path above 40 960) against a
+    stable descending argsort: ranks discard .. discard+k-1, ties to the lower index, ascending index
+    order in the list; one case has a fifth of each row tied at one value."""
+    import torch
+
+    from hyperion_amd.score_norm.adapt_s_norm import lists_to_numpy, topk_rows
+
+    rng = np.random.RandomState(nc + k)
+    A = (rng.randn(n, nc) * 3 + shift).astype(np.float32)
+    if nc == 700:
+        A[:, ::5] = A[:, :1]
+    idx = lists_to_numpy(topk_rows(torch.from_numpy(A).cuda(), k, disc), k)
+    order = np.argsort(-A, axis=1, kind="stable")
+    assert np.array_equal(idx, np.sort(order[:, disc:disc + k], axis=1))
