@@ -1025,9 +1025,13 @@ int launch_gather(const float* X, int64_t n_rows, int nc, int64_t ldx, const uns
     const int64_t groups = (n_rows + R - 1) / R;
     HYPMI_REQUIRE(groups <= 0x7fffffffLL, "gather_stats: too many rows");
     // One workgroup walks all lists for its rows unless there are too few row groups to fill the chip,
-    // in which case the lists are split over blockIdx.y.  (Blocking the lists for L2 residency was
-    // measured and is slower: the kernel is bound by the random LDS gathers, not by the index stream,
-    // and every extra chunk reloads the rows into LDS.)
+    // in which case the lists are split over blockIdx.y.  Measured at 10k rows x 65536 lists x 300 of
+    // 20000 (23.3 ms, 13.7 elements/clk/CU): splitting the lists so that a block of them stays in L2 is
+    // slower with every doubling (24.6 ms at 4 blocks ... 45 ms at 64: each block reloads the rows);
+    // six index loads in flight per lane instead of two change nothing; lists without any bank
+    // conflict (all entries equal) still take 20.7 ms.  Neither the index stream nor the LDS banks
+    // bound the walk; what remains is instruction issue and LDS latency (about seven instructions per
+    // pair of gathered values at four waves per SIMD).
     int64_t chunks = 1;
     while (groups * chunks < 1024 && (n_lists + chunks - 1) / chunks > 4 * GS_THREADS) chunks *= 2;
     if (chunks > 65535) chunks = 65535;

@@ -160,7 +160,17 @@ class PLDABase(HypModel):
         xm, _ = pool_rows(engine.upload(x), ids, mean=True)
         return xm
 
+    @staticmethod
+    def _result(S, *inputs):
+        """Device tensors in give the device matrix back; anything else a `float_cpu()` array."""
+        torch = engine.require_gpu()
+        if all(isinstance(x, torch.Tensor) for x in inputs):
+            return S
+        return engine.to_host(S, float_cpu())
+
     def llr_NvsM(self, x1, x2, ids1=None, ids2=None, method="vavg-lnorm"):
+        """Multi-session scoring (plda_base.py:292-322).  numpy in / numpy out; device tensors in
+        (methods vavg, vavg-lnorm, savg) give a device tensor out."""
         if method == "savg":
             return self._llr_savg(x1, ids1, x2, ids2)
         if method == "book":
@@ -172,7 +182,7 @@ class PLDABase(HypModel):
         plan = self.score_plan(lnorm_first=(method == "vavg-lnorm"))
         G1 = plan.prologue(self._pooled_mean(x1, ids1), SIDE_ENROL)
         G2 = plan.prologue(self._pooled_mean(x2, ids2), SIDE_TEST)
-        return engine.to_host(engine.score(G1, G2), float_cpu())
+        return self._result(engine.score(G1, G2), x1, x2)
 
     def llr_Nvs1(self, x1, x2, ids1=None, method="vavg-lnorm"):
         if method == "savg":
@@ -186,7 +196,7 @@ class PLDABase(HypModel):
         plan = self.score_plan(lnorm_first=(method == "vavg-lnorm"))
         G1 = plan.prologue(self._pooled_mean(x1, ids1), SIDE_ENROL)
         G2 = plan.prologue(engine.upload(x2), SIDE_TEST)
-        return engine.to_host(engine.score(G1, G2), float_cpu())
+        return self._result(engine.score(G1, G2), x1, x2)
 
     def _llr_savg(self, x1, ids1, x2, ids2):
         """Score averaging (plda_base.py:316-322, 347-351).  The score is bilinear in the packed
@@ -199,7 +209,7 @@ class PLDABase(HypModel):
             G1 = pool_rows(G1, ids1, mean=True)[0].contiguous()
         if ids2 is not None:
             G2 = pool_rows(G2, ids2, mean=True)[0].contiguous()
-        return engine.to_host(engine.score(G1, G2), float_cpu())
+        return self._result(engine.score(G1, G2), x1, x2)
 
     def _stats_dev(self, x, ids):
         F_dev, counts = pool_rows(engine.upload(x), ids, mean=False)
