@@ -291,6 +291,24 @@ def refine_scores(S, G1_64, bnd1, G2_64, bnd2, rel_tol=1e-4, err_coeff=ERR_COEFF
     return int(counter.item()) if count else None
 
 
+_staging = {}
+
+
 def to_host(t, dtype):
-    """Device tensor -> numpy array of the host float type."""
-    return t.cpu().numpy().astype(dtype, copy=False)
+    """Device tensor -> numpy array of the host float type.  Large results go through a cached
+    page-locked staging buffer (pageable device-to-host copies run at a fraction of the link rate)
+    and are widened to the host type by torch's threaded copy rather than numpy's serial astype."""
+    torch = _torch()
+    n = t.numel()
+    if n < (1 << 16) or t.dtype != torch.float32:
+        return t.cpu().numpy().astype(dtype, copy=False)
+    buf = _staging.get("buf")
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(n, 1 << 22), dtype=torch.float32, pin_memory=True)
+        _staging["buf"] = buf
+    stage = buf[:n].view(t.shape)
+    stage.copy_(t, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    out = np.empty(tuple(t.shape), dtype=dtype)
+    torch.from_numpy(out).copy_(stage)
+    return out
