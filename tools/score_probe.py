@@ -65,9 +65,3 @@ if lib.hypmi_split_row_bytes(a.kp):
     report("bf16x3", ms, med)
     ms, med = timed(lambda: (engine.split_rows(G1), engine.split_rows(G2)))
     print("split_rows of both sides: %.3f ms" % ms)
-    for dbg in os.environ.get("PROBE_DBG", "").split(","):
-        if dbg:
-            os.environ["HYPMI_SPLIT_DBG"] = dbg
-            ms, med = timed(lambda: engine.score(H1, H2, out=S))
-            print("dbg %s (1 = no stores, 2 = no DMA, 4 = no LDS re-reads): min %.3f ms" % (dbg, ms))
-            os.environ.pop("HYPMI_SPLIT_DBG")
