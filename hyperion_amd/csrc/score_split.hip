@@ -117,8 +117,10 @@ __device__ __forceinline__ void lds_dma_16_uniform(const void* sbase, unsigned v
 // PREVIOUS tile's scores are spread between the MFMA groups of the current one, so the matrix pipe
 // only pauses for the three-way sum at the end of a tile.  Other waves take the plain order
 // (stage, multiply, guarded stores).
+// Up to 160 coordinates (KS2 <= 5) a wave needs fewer than 256 registers and two workgroups share a
+// CU; wider rows keep up to 240 registers of stationary operand alone and run one wave per SIMD.
 template <int KS2>  // k-steps of 32 coordinates
-__global__ __launch_bounds__(256, 2) void score_split_kernel(const uint4* __restrict__ H1,
+__global__ __launch_bounds__(256, (KS2 <= 5 ? 2 : 1)) void score_split_kernel(const uint4* __restrict__ H1,
                                                              const uint4* __restrict__ H2,
                                                              float* __restrict__ S, int64_t n1,
                                                              int64_t n2, int64_t ldo,
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(const uint4* __rest
     constexpr int PIECES = (TILE_SLOTS + 63) / 64;  // LDS-DMA instructions per tile
     constexpr int BUF_SLOTS = PIECES * 64;          // the last piece runs past the tile (see hypmi_split_bytes)
     constexpr int NPW = (PIECES + 3) / 4;           // pieces per wave
-    __shared__ __attribute__((aligned(16))) uint4 tile[2 * BUF_SLOTS];
+    extern __shared__ __attribute__((aligned(16))) uint4 tile[];  // 2 * BUF_SLOTS (up to 128 KiB)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -318,24 +320,25 @@ __global__ __launch_bounds__(256, 2) void score_split_kernel(const uint4* __rest
 #endif
 }
 
-#define HYPMI_DEFINE_SPLIT_LAUNCH(KS2)                                                            \
-    static int launch_split_##KS2(const uint4* H1, int64_t n1, const uint4* H2, int64_t n2, float* S,  \
-                                  int64_t lds, hipStream_t stream) {                                   \
-        LaunchGeom g;                                                                                  \
-        int rc = launch_geometry(n1, n2, 128, &g);                                                     \
-        if (rc != HYPMI_OK) return rc;                                                                 \
-        hipLaunchKernelGGL((score_split_kernel<KS2>), dim3((unsigned)g.gx, (unsigned)g.gy), dim3(256), \
-                           0, stream, H1, H2, S, n1, n2, lds, g.tiles_per_chunk);                      \
-        HYPMI_HIP(hipGetLastError());                                                                  \
-        return HYPMI_OK;                                                                               \
-    }
+template <int KS2>
+static int launch_split(const uint4* H1, int64_t n1, const uint4* H2, int64_t n2, float* S, int64_t lds,
+                        hipStream_t stream) {
+    constexpr int PIECES = (32 * split_row_slots(2 * KS2) + 63) / 64;
+    constexpr int LDS_BYTES = 2 * PIECES * 64 * 16;
+    static_assert(LDS_BYTES <= 160 * 1024, "tile buffers exceed the LDS");
+    LaunchGeom g;
+    int rc = launch_geometry(n1, n2, 128, &g);
+    if (rc != HYPMI_OK) return rc;
+    if (LDS_BYTES > 48 * 1024)
+        HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_split_kernel<KS2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    hipLaunchKernelGGL((score_split_kernel<KS2>), dim3((unsigned)g.gx, (unsigned)g.gy), dim3(256), LDS_BYTES,
+                       stream, H1, H2, S, n1, n2, lds, g.tiles_per_chunk);
+    HYPMI_HIP(hipGetLastError());
+    return HYPMI_OK;
+}
 
-HYPMI_DEFINE_SPLIT_LAUNCH(1)
-HYPMI_DEFINE_SPLIT_LAUNCH(2)
-HYPMI_DEFINE_SPLIT_LAUNCH(3)
-HYPMI_DEFINE_SPLIT_LAUNCH(4)
-HYPMI_DEFINE_SPLIT_LAUNCH(5)
-#undef HYPMI_DEFINE_SPLIT_LAUNCH
+constexpr int SPLIT_MAX_KS2 = 10;
 
 }  // namespace hypmi_detail
 
@@ -345,7 +348,7 @@ using namespace hypmi_detail;
 static int split_ksteps(int kp) {
     if (kp <= 0 || kp % 8 != 0) return 0;
     const int ks2 = (kp + 31) / 32;
-    return ks2 <= 5 ? ks2 : 0;
+    return ks2 <= SPLIT_MAX_KS2 ? ks2 : 0;
 }
 
 extern "C" int64_t hypmi_split_row_bytes(int kp) {
@@ -391,10 +394,15 @@ extern "C" int hypmi_score_split(const void* H1_, int64_t n1, const void* H2_, i
     const uint4* H1 = static_cast<const uint4*>(H1_);
     const uint4* H2 = static_cast<const uint4*>(H2_);
     switch (ks) {
-        case 1: return launch_split_1(H1, n1, H2, n2, S, lds, stream);
-        case 2: return launch_split_2(H1, n1, H2, n2, S, lds, stream);
-        case 3: return launch_split_3(H1, n1, H2, n2, S, lds, stream);
-        case 4: return launch_split_4(H1, n1, H2, n2, S, lds, stream);
-        default: return launch_split_5(H1, n1, H2, n2, S, lds, stream);
+        case 1: return launch_split<1>(H1, n1, H2, n2, S, lds, stream);
+        case 2: return launch_split<2>(H1, n1, H2, n2, S, lds, stream);
+        case 3: return launch_split<3>(H1, n1, H2, n2, S, lds, stream);
+        case 4: return launch_split<4>(H1, n1, H2, n2, S, lds, stream);
+        case 5: return launch_split<5>(H1, n1, H2, n2, S, lds, stream);
+        case 6: return launch_split<6>(H1, n1, H2, n2, S, lds, stream);
+        case 7: return launch_split<7>(H1, n1, H2, n2, S, lds, stream);
+        case 8: return launch_split<8>(H1, n1, H2, n2, S, lds, stream);
+        case 9: return launch_split<9>(H1, n1, H2, n2, S, lds, stream);
+        default: return launch_split<10>(H1, n1, H2, n2, S, lds, stream);
     }
 }

@@ -465,7 +465,7 @@ def _decode_split(H, n, kp):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kp", [16, 64, 152])
+@pytest.mark.parametrize("kp", [16, 64, 152, 232, 304])
 def test_split_rows_are_exact(kp):
     """x0 + x1 + x2 reproduces every fp32 value bit for bit (the split kernel's only approximation is
     then the three dropped partial products); non-finite values keep their class.  (Below 2^-110 the
@@ -499,7 +499,7 @@ def test_split_rows_are_exact(kp):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kp", [16, 32, 64, 96, 128, 152])
+@pytest.mark.parametrize("kp", [16, 32, 64, 96, 128, 152, 192, 232, 264, 304, 320])
 @pytest.mark.parametrize("n1,n2", [(1, 1), (31, 33), (128, 2048), (333, 2100), (700, 4133)])
 def test_split_score_matches_float64(kp, n1, n2):
     """bf16 three-way split kernel against a float64 product of the same fp32 rows: the error stays
