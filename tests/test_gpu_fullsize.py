@@ -165,3 +165,44 @@ def test_adapt_s_norm_10k_enrol_by_1m_test():
     ref = O.adapt_s_norm(O.llr_1vs1(model, ye, yt), O.llr_1vs1(model, yc, yt), O.llr_1vs1(model, ye, yc), nbest, 0)
     got = _host64(out[torch.from_numpy(es).cuda()][:, torch.from_numpy(ts).cuda()])
     _assert_close(got, ref, tol=2e-5)
+
+
+def test_adapt_s_norm_1m_enrol_shard_of_tests():
+    """One GPU's view of the 1M x 1M configuration: all 1 000 000 enrolment models (an 80 GB
+    enrol-vs-cohort panel, one million top-300 lists) against a shard of 8192 tests, streamed through
+    the reduce callback in chunks; sampled entries against the oracle, and the streamed sums against
+    the sums of the same blocks."""
+    import torch
+
+    from hyperion_amd.backend import PLDABackend
+
+    ne, nt, nc, d, K, nbest = 1_000_000, 8192, 20_000, 200, 150, 300
+    model = synth.make_splda(d, K)
+    plda = _models()(model)
+
+    def unit(n, seed):
+        x = _randn(n, d, seed)
+        return x * (d ** 0.5) / x.norm(dim=1, keepdim=True)
+
+    xe, xc, xt = unit(ne, 41), unit(nc, 42), unit(nt, 43)
+    be = PLDABackend(plda, None, nbest=nbest, test_chunk=4096)
+    coh = be.prepare_cohort(xe, xc)
+    assert tuple(coh["A_ec"].shape) == (ne, nc)
+    rng = np.random.RandomState(6)
+    es = np.concatenate([[0, ne - 1, 65_535, 65_536], rng.randint(0, ne, 4)])
+    ts = np.concatenate([[0, nt - 1, 4095, 4096], rng.randint(0, nt, 4)])
+    es_dev = torch.from_numpy(es).cuda()
+    picked, sums = {}, []
+
+    def sink(c0, block):  # block: [n_enrol, chunk] normalised scores of tests c0 .. c0 + chunk
+        sums.append(float(block.sum(dtype=torch.float64)))
+        for j, t in enumerate(ts):
+            if c0 <= t < c0 + block.shape[1]:
+                picked[j] = block[es_dev, t - c0].double().cpu().numpy()
+
+    assert be.score_snorm(xt, coh, reduce=sink) is None
+    assert len(sums) == 2 and all(np.isfinite(sums)) and len(picked) == len(ts)
+    got = np.stack([picked[j] for j in range(len(ts))], axis=1)
+    ye, yt, yc = _host64(xe[es_dev]), _host64(xt[torch.from_numpy(ts).cuda()]), _host64(xc)
+    ref = O.adapt_s_norm(O.llr_1vs1(model, ye, yt), O.llr_1vs1(model, yc, yt), O.llr_1vs1(model, ye, yc), nbest, 0)
+    _assert_close(got, ref, tol=2e-5)
