@@ -715,26 +715,40 @@ __device__ __forceinline__ void unpack<4>(const float4& v, float (&o)[4]) {
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
 }
 
-template <int R, bool MASK>
+// IN_LDS = false (R = 1 only) is the variant for cohorts whose row does not fit in LDS: the values
+// are gathered from the row in global memory (L2), an order of magnitude slower per element.
+template <int R, bool MASK, bool IN_LDS = true>
 __global__ __launch_bounds__(GS_THREADS) void gather_stats_kernel(
     const float* __restrict__ X, int64_t ldx, int64_t n_rows, const unsigned char* __restrict__ mask,
     int64_t ldm, int nc, const uint16_t* __restrict__ idx8, int64_t ldi, int k, int64_t Q,
     int64_t q_per_block, float floor_, float* __restrict__ mean, float* __restrict__ istd, int64_t ldo) {
+    static_assert(IN_LDS || R == 1, "rows gathered from global memory are taken one at a time");
     typedef typename VecR<R>::type vec_t;
     extern __shared__ __attribute__((aligned(16))) float xr[];
-    unsigned char* mr = reinterpret_cast<unsigned char*>(xr + (size_t)nc * R);
     const int tid = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * R;
+    if (IN_LDS) {
+        unsigned char* mw = reinterpret_cast<unsigned char*>(xr + (size_t)nc * R);
 #pragma unroll
-    for (int rr = 0; rr < R; ++rr) {
-        const bool live = r0 + rr < n_rows;
-        const float* src = X + (r0 + rr) * ldx;
-        for (int c = tid; c < nc; c += GS_THREADS) xr[c * R + rr] = live ? __builtin_nontemporal_load(src + c) : 0.f;
-        if (MASK)
-            for (int c = tid; c < nc; c += GS_THREADS) mr[c * R + rr] = live ? mask[(r0 + rr) * ldm + c] : 0;
+        for (int rr = 0; rr < R; ++rr) {
+            const bool live = r0 + rr < n_rows;
+            const float* src = X + (r0 + rr) * ldx;
+            for (int c = tid; c < nc; c += GS_THREADS)
+                xr[c * R + rr] = live ? __builtin_nontemporal_load(src + c) : 0.f;
+            if (MASK)
+                for (int c = tid; c < nc; c += GS_THREADS) mw[c * R + rr] = live ? mask[(r0 + rr) * ldm + c] : 0;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    const vec_t* xv = reinterpret_cast<const vec_t*>(xr);
+    // the address space of the gathered operand is a compile-time property of the instantiation
+    const auto xv = [&]() {
+        if constexpr (IN_LDS) return reinterpret_cast<const vec_t*>(xr);
+        else return reinterpret_cast<const vec_t*>(X + r0 * ldx);
+    }();
+    const auto mr = [&]() {
+        if constexpr (IN_LDS) return reinterpret_cast<const unsigned char*>(xr + (size_t)nc * R);
+        else return mask + (MASK ? r0 * ldm : 0);
+    }();
     const int kg = k >> 3, krem = k & 7;
     const int64_t q0 = (int64_t)blockIdx.y * q_per_block;
     const int64_t q1 = (q0 + q_per_block < Q) ? q0 + q_per_block : Q;
@@ -1014,13 +1028,14 @@ extern "C" int hypmi_topk_rows(const float* A, int64_t n_rows, int nc, int64_t l
 }
 
 namespace {
-template <int R, bool MASK>
+template <int R, bool MASK, bool IN_LDS = true>
 int launch_gather(const float* X, int64_t n_rows, int nc, int64_t ldx, const unsigned char* mask,
                   int64_t ldm, const uint16_t* idx8, int64_t ldi, int k, int64_t n_lists, float std_floor,
                   float* mean, float* istd, int64_t ldo, hipStream_t stream) {
-    const int64_t lds_need = round_up((int64_t)nc * R * 4 + (MASK ? (int64_t)nc * R : 0), 16);
+    const int64_t lds_need =
+        IN_LDS ? round_up((int64_t)nc * R * 4 + (MASK ? (int64_t)nc * R : 0), 16) : 16;
     if (lds_need > 48 * 1024)
-        HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_stats_kernel<R, MASK>),
+        HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_stats_kernel<R, MASK, IN_LDS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
     const int64_t groups = (n_rows + R - 1) / R;
     HYPMI_REQUIRE(groups <= 0x7fffffffLL, "gather_stats: too many rows");
@@ -1037,7 +1052,7 @@ int launch_gather(const float* X, int64_t n_rows, int nc, int64_t ldx, const uns
     if (chunks > 65535) chunks = 65535;
     const int64_t q_per_block = round_up((n_lists + chunks - 1) / chunks, GS_THREADS);
     chunks = (n_lists + q_per_block - 1) / q_per_block;
-    hipLaunchKernelGGL((gather_stats_kernel<R, MASK>), dim3((unsigned)groups, (unsigned)chunks),
+    hipLaunchKernelGGL((gather_stats_kernel<R, MASK, IN_LDS>), dim3((unsigned)groups, (unsigned)chunks),
                        dim3(GS_THREADS), lds_need, stream, X, ldx, n_rows, mask, ldm, nc, idx8, ldi, k,
                        n_lists, q_per_block, std_floor, mean, istd, ldo);
     HYPMI_HIP(hipGetLastError());
@@ -1057,7 +1072,11 @@ extern "C" int hypmi_gather_stats(const float* X, int64_t n_rows, int nc, int64_
     HYPMI_REQUIRE(aligned16(idx_t), "gather_stats: index lists must be 16-byte aligned");
     if (n_rows == 0 || n_lists == 0) return HYPMI_OK;
     const int64_t per_row = (int64_t)nc * 4 + (mask ? nc : 0);
-    HYPMI_REQUIRE(per_row <= MAX_LDS_BYTES, "gather_stats: cohort of %d does not fit in LDS", nc);
+    if (per_row > MAX_LDS_BYTES)  // one row does not fit in LDS: gather it from global memory
+        return mask ? launch_gather<1, true, false>(X, n_rows, nc, ldx, mask, ldm, idx_t, ldi, k, n_lists,
+                                                    std_floor, mean, istd, ldo, stream)
+                    : launch_gather<1, false, false>(X, n_rows, nc, ldx, mask, ldm, idx_t, ldi, k, n_lists,
+                                                     std_floor, mean, istd, ldo, stream);
     // as many rows per workgroup as LDS holds (each index fetched is reused for all of them)
     int R = 1;
     if (4 * per_row <= MAX_LDS_BYTES && n_rows >= 4) R = 4;

@@ -562,3 +562,24 @@ def test_topk_rows_matches_stable_argsort(n, nc, k, disc, shift):
     idx = lists_to_numpy(topk_rows(torch.from_numpy(A).cuda(), k, disc), k)
     order = np.argsort(-A, axis=1, kind="stable")
     assert np.array_equal(idx, np.sort(order[:, disc:disc + k], axis=1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("masked", [False, True])
+def test_adapt_s_norm_cohort_larger_than_lds(masked):
+    """45 000 cohort members: neither the register-resident top-k (40 960) nor an LDS-resident row
+    (40 960 fp32) applies; the workspace top-k and the global-memory gather give the same result."""
+    from hyperion_amd.score_norm import AdaptSNorm
+
+    rng = np.random.RandomState(17)
+    ne, nt, nc = 6, 9, 45_000
+    sc = rng.randn(ne, nt) * 4
+    ct = rng.randn(nc, nt) * 3 - 5
+    ec = rng.randn(ne, nc) * 3 - 5
+    kw = {}
+    if masked:
+        kw = {"mask_coh_test": rng.rand(nc, nt) > 0.1, "mask_enr_coh": rng.rand(ne, nc) > 0.1}
+    got = AdaptSNorm(nbest=200, nbest_discard=3).predict(sc, ct, ec, **kw)
+    ref = O.adapt_s_norm(sc, ct, ec, 200, 3, **kw)
+    err = np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)
+    assert err.max() <= 2e-5, float(err.max())
