@@ -247,6 +247,27 @@ int hypmi_norm_apply(const float* S, int64_t lds, int64_t ne, int64_t nt, const 
                      const float* iz, const float* mt, const float* it, float* out, int64_t ldo,
                      void* stream);
 
+/* ---- score sink (hyperion/utils/trial_scores.py, hyperion/metrics) ---------------------------- */
+
+/* Target / non-target histograms and moments of a device score block S[ne x nt], ADDED to hist and
+ * mom (the caller zeroes them before the first block; any number of blocks of one trial set may be
+ * added).  Stands in for TrialScores.get_tar_non (trial_scores.py:342-357: scores[key.tar],
+ * scores[key.non]) followed by the sort of all scores (metrics/roc.py:67-72) when the matrix is too
+ * large to leave the device.  Labels, one of:
+ *   keys : key_e[ne], key_t[nt] int32 (both or neither); a trial is a target when the keys are equal
+ *          and is no trial when either key is negative;
+ *   masks: tar (and optionally non) uint8 [ne x ldm] as in TrialKey.tar / .non; without `non` every
+ *          trial that is not a target is a non-target;
+ *   none : every score counts as a non-target.
+ * Bin of a score s: floor((s - lo) * (float)nbins / (hi - lo)) evaluated in float32, clamped to
+ * 0 .. nbins-1 (1 <= nbins <= 8192).  hist: uint64 [2 x nbins], non-targets first.  mom: float64
+ * [2 x 4], per class: count, sum, sum of squares, number of non-finite scores (which are left out of
+ * the bins and the sums). */
+int hypmi_score_hist(const float* S, int64_t lds, int64_t ne, int64_t nt, const int32_t* key_e,
+                     const int32_t* key_t, const unsigned char* tar, const unsigned char* non,
+                     int64_t ldm, float lo, float hi, int nbins, unsigned long long* hist, double* mom,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif
