@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (256 CU x 256 flop/clk x 2.4 GHz)
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # dense bf16 matrix peak (256 CU x 4096 flop/clk x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
+LDS_PEAK_GBS = 256 * 128 * 2.4  # GB/s: 128 bytes per clock and CU
 
 WORKLOADS = {
     # n_enrol, n_test per GPU, input dim, LDA dim, y_dim; asnorm: cohort size and nbest
@@ -35,6 +36,12 @@ WORKLOADS = {
     "splda_vox1": dict(n_enrol=4874, n_test=4874, d=512, lda=None, K=150),
     "asnorm_10k_1m": dict(n_enrol=10_000, n_test=1_000_000, d=512, lda=200, K=150, n_coh=20_000, nbest=300),
     "asnorm_10k_128k": dict(n_enrol=10_000, n_test=131_072, d=512, lda=200, K=150, n_coh=20_000, nbest=300),
+    # one GPU's share of the 1M x 1M matrix on 8 GPUs (125 000 tests per GPU: `--gpus 8` is the whole
+    # job); the normalised scores are never kept, every block goes into target / non-target histograms
+    "asnorm_1m_125k": dict(n_enrol=1_000_000, n_test=125_000, d=512, lda=200, K=150, n_coh=20_000, nbest=300,
+                           sink=True, test_chunk=4096),
+    "asnorm_100k_16k": dict(n_enrol=100_000, n_test=16_384, d=512, lda=200, K=150, n_coh=20_000, nbest=300,
+                            sink=True, test_chunk=4096),
 }
 
 
@@ -131,16 +138,33 @@ def asnorm_stage(plda, preproc, cfg, n_test, steps, warmup, rank, world=1):
     from hyperion_amd import engine
     from hyperion_amd.backend import PLDABackend
 
-    ne, nc, nbest = 10_000, cfg.get("n_coh", 20_000), cfg.get("nbest", 300)
-    be = PLDABackend(plda, preproc, nbest=nbest, test_chunk=65536)
-    xe = engine.upload(make_inputs(cfg, ne, 41))
-    xc = engine.upload(make_inputs(cfg, nc, 42))
-    xt = engine.upload(make_inputs(cfg, n_test, 43 + 1000 * rank))
-    out = torch.empty((ne, engine.round_up(n_test, 32)), dtype=torch.float32, device="cuda")[:, :n_test]
+    ne = cfg["n_enrol"] if "n_coh" in cfg else 10_000  # the default workload appends a 10k-enrol stage
+    nc, nbest = cfg.get("n_coh", 20_000), cfg.get("nbest", 300)
+    sink = bool(cfg.get("sink"))
+    be = PLDABackend(plda, preproc, nbest=nbest, test_chunk=cfg.get("test_chunk", 65536))
+    if sink:  # too large for host-side generation and for a materialised result
+        xe, ke = device_xvectors(ne, cfg["d"], 41)
+        xc, _ = device_xvectors(nc, cfg["d"], 42)
+        xt, kt = device_xvectors(n_test, cfg["d"], 43 + 1000 * rank)
+        out = None
+    else:
+        xe = engine.upload(make_inputs(cfg, ne, 41))
+        xc = engine.upload(make_inputs(cfg, nc, 42))
+        xt = engine.upload(make_inputs(cfg, n_test, 43 + 1000 * rank))
+        out = torch.empty((ne, engine.round_up(n_test, 32)), dtype=torch.float32, device="cuda")[:, :n_test]
+    hists = []
 
     def step():
         coh = be.prepare_cohort(xe, xc, rank=rank, world=world)  # one all-gather of top-k lists
-        be.score_snorm(xt, coh, out=out)
+        if sink:
+            from hyperion_amd.metrics import TrialHistogram
+
+            h = TrialHistogram(-40.0, 40.0, 4096)
+            be.score_snorm(xt, coh, reduce=h.sink(ke, kt))
+            h.all_reduce()  # 2 x 4096 counts + 8 moments
+            hists[:] = [h]
+        else:
+            be.score_snorm(xt, coh, out=out)
 
     for _ in range(warmup):
         step()
@@ -150,11 +174,31 @@ def asnorm_stage(plda, preproc, cfg, n_test, steps, warmup, rank, world=1):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    return {"workload": "chain+SPLDA+AdaptSNorm: %d enrol x %d test, cohort %d, nbest %d, one GPU"
-                        % (ne, n_test, nc, nbest),
-            "value": ne * n_test / dt, "unit": "normalised scores/s", "ms_per_step": dt * 1e3,
-            "gather_GBs": 2.0 * nbest * 4 * ne * n_test / dt / 1e9,
-            "checksum": float(out.sum(dtype=torch.float64).item())}, be, (xe, xc, xt, out)
+    st = {"workload": "chain+SPLDA+AdaptSNorm: %d enrol x %d test per GPU, cohort %d, nbest %d%s"
+                      % (ne, n_test, nc, nbest, ", streamed into tar/non histograms" if sink else ""),
+          "value": ne * n_test / dt, "unit": "normalised scores/s", "ms_per_step": dt * 1e3,
+          "gather_GBs": 2.0 * nbest * 4 * ne * n_test / dt / 1e9}
+    if sink:
+        m = hists[0].moments()
+        st["sink"] = {"trials": m["tar"]["count"] + m["non"]["count"], "tar": m["tar"], "non": m["non"],
+                      "eer": hists[0].eer(), "min_dcf_0.05": hists[0].min_dcf(0.05)[0]}
+    else:
+        st["checksum"] = float(out.sum(dtype=torch.float64).item())
+    return st, be, (xe, xc, xt, out)
+
+
+def device_xvectors(n, d, seed, num_centers=10_000):
+    """Raw x-vectors drawn on the device (0.5 x class centre + unit noise, class = row % num_centers):
+    the shape of synth.raw_xvectors without a host round trip, for the million-vector workloads."""
+    import torch
+
+    g = torch.Generator(device="cuda").manual_seed(20)
+    C = torch.randn((num_centers, d), device="cuda", generator=g)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    cls = torch.arange(n, device="cuda") % num_centers
+    x = torch.randn((n, d), device="cuda", generator=g)
+    x += 0.5 * C[cls]
+    return x, cls.to(torch.int32)
 
 
 def asnorm_check(be, bufs, chain, model, cfg):
@@ -164,6 +208,8 @@ def asnorm_check(be, bufs, chain, model, cfg):
 
     xe, xc, xt, out = bufs
     r, c = 8, 64
+    if out is None:  # streamed workload: normalise the slab's tests again, materialised
+        out = be.score_snorm(xt[:c], be.prepare_cohort(xe[:r], xc))
     f = lambda t, n: O.chain_predict(t[:n].cpu().numpy().astype(np.float64), chain)  # noqa: E731
     ye, yt, yc = f(xe, r), f(xt, c), f(xc, xc.shape[0])
     ref = O.adapt_s_norm(O.llr_1vs1(model, ye, yt), O.llr_1vs1(model, yc, yt), O.llr_1vs1(model, ye, yc),
@@ -359,7 +405,7 @@ def main_asnorm(args, cfg, chain, model, plda, preproc, plan, world, rank, dist)
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    ne, nt = 10_000, cfg["n_test"]
+    ne, nt = cfg["n_enrol"], cfg["n_test"]
     out = {
         "metric": "PLDA trial scores/sec (512-d, SPLDA+AS-norm)", "value": ne * nt * world / dt,
         "unit": "scores/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -367,11 +413,16 @@ def main_asnorm(args, cfg, chain, model, plda, preproc, plan, world, rank, dist)
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.workload + ": " + st["workload"], "parallelism":
                    "test rows sharded over %d GPU(s), enrol and cohort replicated" % world},
-        "roofline": {"kernel": "gather_stats_kernel<2,false>", "bound": "hbm",
-                     "note": "bound by random LDS gathers, not HBM; achieved = gathered bytes / step time",
-                     "achieved": st["gather_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": st["gather_GBs"] / HBM_PEAK_GBS, "traffic": None},
+        # the dominant kernel gathers from LDS, not from HBM: 2 x nbest fp32 values per normalised score
+        # against the LDS bandwidth of the chip (256 CUs x 128 B/clk x 2.4 GHz)
+        "roofline": {"kernel": "gather_stats_kernel<2,false>", "bound": "lds",
+                     "note": "random LDS gathers; achieved = gathered bytes (2 x nbest x 4 B per normalised "
+                             "score) / step time, the step including scoring, top-k and the sink",
+                     "achieved": st["gather_GBs"], "peak": LDS_PEAK_GBS, "unit": "GB/s",
+                     "frac": st["gather_GBs"] / LDS_PEAK_GBS, "traffic": None},
     }
+    if "sink" in st:
+        out["sink"] = st["sink"]
     if rank == 0 and not args.no_check and chain is not None:
         out["parity"] = {"max_err_over_max_abs_1": asnorm_check(be, bufs, chain, model, cfg)}
     if rank == 0:
