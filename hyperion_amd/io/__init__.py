@@ -1,0 +1,3 @@
+"""Readers and writers of the vector files the scoring path starts from (subset of hyperion/io)."""
+from .ark import ArkDataWriter, RandomAccessArkDataReader  # noqa: F401
+from .factory import RandomAccessDataReaderFactory  # noqa: F401

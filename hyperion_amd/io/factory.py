@@ -1,0 +1,49 @@
+"""Read specifiers `scp[,options]:file` -> reader objects (hyperion/io/rw_specifiers.py:323-420,
+hyperion/io/data_rw_factory.py:139-173).  Ark archives behind scp files are supported; HDF5 needs
+h5py, which this build does not have."""
+import re
+
+from .ark import RandomAccessArkDataReader
+
+
+class RandomAccessDataReaderFactory(object):
+    @staticmethod
+    def parse(rspecifier):
+        """-> (kind, path, permissive) with kind 'scp' or 'ark' or 'h5'."""
+        fields = rspecifier.strip().split(":")
+        if len(fields) == 1:
+            assert len(fields[0]) > 0
+            return "h5", fields[0], False  # a bare path is an HDF5 archive (rw_specifiers.py:326-328)
+        if len(fields) != 2:
+            raise ValueError("Two many fields (%d>2) in wspecifier %s" % (len(fields), rspecifier))
+        kind, permissive = None, False
+        for option in fields[0].strip().split(","):
+            if option in ("scp", "ark", "h5"):
+                assert kind is None
+                kind = option
+            elif option == "p":
+                permissive = True
+            elif option not in ("o", "s", "cs", "bg"):
+                raise ValueError("Wrong wspecifier options %s" % fields[0])
+        assert kind is not None, "Wrong wspecifier options %s" % fields[0]
+        path = fields[1].strip()
+        if kind == "scp":
+            with open(path, "r") as f:
+                second = f.readline().strip().split(" ")[1]
+            if re.match(r".*\.h5(?:.[0-9]+:[0-9]+.)?$", second) is not None:
+                kind = "scp-h5"
+        return kind, path, permissive
+
+    @staticmethod
+    def create(rspecifier, path_prefix=None, transform=None, scp_sep=" "):
+        kind, path, permissive = RandomAccessDataReaderFactory.parse(rspecifier)
+        if kind == "scp":
+            return RandomAccessArkDataReader(path, path_prefix, transform=transform, permissive=permissive,
+                                             scp_sep=scp_sep)
+        if kind == "ark":
+            raise ValueError("Random access to Ark file %s needs a script file" % path)
+        raise NotImplementedError("HDF5 vector files need h5py, which is not available; use scp:... over ark files")
+
+    @staticmethod
+    def filter_args(**kwargs):
+        return dict((k, kwargs[k]) for k in ("scp_sep", "path_prefix") if k in kwargs)

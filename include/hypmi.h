@@ -8,7 +8,8 @@
  *   - every function returns 0 on success or a negative HYPMI_E* code; hypmi_last_error() gives a
  *     thread-local message for the last failure on the calling thread;
  *   - all data pointers are DEVICE pointers owned by the caller (the Python shim hands over
- *     torch-allocated storage); the library owns only opaque hypmi_plan objects;
+ *     torch-allocated storage); the library owns only opaque hypmi_plan objects; the hypmi_ark_*
+ *     loader functions are the exception: they run on the host and take host pointers;
  *   - all matrices are row-major fp32 unless stated; leading dimensions are in elements;
  *     row starts must be 16-byte aligned (base pointer 16-byte aligned, ld a multiple of 4);
  *   - calls are stream-ordered on `stream` (a hipStream_t passed as void*) and do not block the
@@ -28,6 +29,7 @@ extern "C" {
 #define HYPMI_EINVAL (-1)  /* bad argument (shape, alignment, null pointer) */
 #define HYPMI_EHIP (-2)    /* a HIP runtime call failed                     */
 #define HYPMI_ENOMEM (-3)  /* device allocation failed                      */
+#define HYPMI_EIO (-4)     /* a file could not be read as asked             */
 
 #define HYPMI_MAX_SEG 4
 
@@ -246,6 +248,28 @@ int hypmi_row_meanstd(const float* X, int64_t n_rows, int nc, int64_t ldx, const
 int hypmi_norm_apply(const float* S, int64_t lds, int64_t ne, int64_t nt, const float* mz,
                      const float* iz, const float* mt, const float* it, float* out, int64_t ldo,
                      void* stream);
+
+/* ---- x-vector loading (HOST functions: host pointers, no device, no stream) ------------------- */
+
+/* Shape of the record at byte `offset` of a Kaldi binary archive (the position an scp line names,
+ * hyperion/utils/scp_list.py:160-201; header layout hyperion/utils/kaldi_matrix.py:163-178):
+ * vectors report rows = 1, is_matrix = 0; elem_bytes is 4 (float32) or 8 (float64). */
+int hypmi_ark_probe(const char* archive, int64_t offset, int32_t* rows, int32_t* cols,
+                    int32_t* elem_bytes, int32_t* is_matrix);
+
+/* Reads n vector records (or one-row matrices) of `dim` elements into the rows of out[n x ld]
+ * (float32, or float64 when out_f64 != 0; records of the other width are converted).  Record i lives
+ * in archives[archive_of[i]] at offsets[i] and goes to row rows[i] (NULL: row i; rows < n), so that a
+ * caller can pass the records in file order, where neighbours are fetched with one read, whatever
+ * the order of its key list.  Replaces the per-key loop of
+ * RandomAccessArkDataReader.read + the stacking of DataReader._squeeze
+ * (hyperion/io/ark_data_reader.py:554-622, data_reader.py:59-83) for x-vector files; `out` is meant
+ * to be page-locked so that one hipMemcpyAsync follows.  n_threads workers read disjoint ranges with
+ * pread.  Any record that is missing, truncated, compressed, text, not a vector or of another
+ * dimension fails the call (HYPMI_EIO, the message names the record). */
+int hypmi_ark_read_vectors(const char* const* archives, int32_t n_archives, const int32_t* archive_of,
+                           const int64_t* offsets, const int64_t* rows, int64_t n, int32_t dim,
+                           int32_t out_f64, void* out, int64_t ld, int32_t n_threads);
 
 /* ---- score sink (hyperion/utils/trial_scores.py, hyperion/metrics) ---------------------------- */
 

@@ -1,0 +1,90 @@
+"""From trial lists and an x-vector archive to scores: the loader feeding the device path, whole
+and split over the reference's job grid (one part per GPU rank), against the oracle on the vectors
+the reference's own reader returned (tests/golden/trials/expected.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+import synth
+from conftest import GOLDEN
+from oracle import plda_ref as O
+
+pytestmark = pytest.mark.gpu
+DIR = os.path.join(GOLDEN, "trials")
+
+
+@pytest.fixture()
+def exp(monkeypatch):
+    monkeypatch.chdir(DIR)
+    return np.load(os.path.join(DIR, "expected.npz"), allow_pickle=False)
+
+
+def _model_and_chain():
+    rng = np.random.RandomState(4)
+    chain = [("cw", 0.1 * rng.randn(24), rng.randn(24, 24) / 5), ("lnorm", None, None),
+             ("lda", 0.1 * rng.randn(24), rng.randn(24, 16) / 5)]
+    return synth.make_splda(16, 6), chain
+
+
+def _objects(m, chain):
+    from hyperion_amd.pdfs.plda import SPLDA
+    from hyperion_amd.transforms import LDA, CentWhiten, LNorm, TransformList
+
+    tl = TransformList([CentWhiten(mu=chain[0][1], T=chain[0][2], name="cw"), LNorm(name="ln"),
+                        LDA(mu=chain[2][1], T=chain[2][2], name="lda")])
+    return SPLDA(mu=m["mu"], V=m["V"], W=m["W"]), tl
+
+
+def test_read_device_equals_reference_vectors(exp):
+    from hyperion_amd.io import RandomAccessArkDataReader
+
+    xd = RandomAccessArkDataReader("vectors.scp").read_device(list(exp["all_keys"]))
+    assert xd.is_cuda and xd.stride(0) % 4 == 0 and xd.data_ptr() % 16 == 0
+    assert np.array_equal(xd.cpu().numpy(), exp["all_x"])
+
+
+def test_reader_with_chain_then_scores(exp):
+    """TrialDataReader(preproc=chain).read() + llr_1vs1, the flow of eval-plda-1vs1
+    (hyperion/bin/eval-plda-1vs1.py:40-60), numpy in and out."""
+    from hyperion_amd.helpers import TrialDataReader
+
+    m, chain = _model_and_chain()
+    plda, tl = _objects(m, chain)
+    x_e, x_t, info, ndx = TrialDataReader("scp:vectors.scp", "trials.ndx", "enroll.lst", preproc=tl).read()
+    ye, yt = O.chain_predict(exp["full_x_e"].astype(float), chain), O.chain_predict(exp["full_x_t"].astype(float), chain)
+    assert np.allclose(x_e, ye, rtol=1e-4, atol=1e-5) and np.allclose(x_t, yt, rtol=1e-4, atol=1e-5)
+    got = plda.llr_1vs1(x_e, x_t)
+    ref = O.llr_1vs1(m, ye, yt)
+    assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)) <= 1e-4
+
+
+def test_job_grid_parts_tile_the_full_matrix(exp):
+    """Every (model part, segment part) job reads its own vectors onto the device, runs the chain
+    there (device tensors in, device tensors out) and scores its block with multi-session enrolment;
+    the blocks tile the full matrix, which matches the oracle.  A rank of a multi-GPU run is one
+    segment part."""
+    from hyperion_amd.helpers import TrialDataReader
+
+    m, chain = _model_and_chain()
+    plda, tl = _objects(m, chain)
+    x_e, x_t, info, ndx = TrialDataReader("scp:vectors.scp", "trials.ndx", "enroll.lst").read_device()
+    ids = np.unique(info, return_inverse=True)[1]
+    full = plda.llr_Nvs1(tl.predict(x_e), tl.predict(x_t), ids1=ids, method="vavg").cpu().numpy()
+    ye = O.chain_predict(exp["full_x_e"].astype(float), chain)
+    yt = O.chain_predict(exp["full_x_t"].astype(float), chain)
+    ref = O.llr_Nvs1(m, ye, yt, ids1=ids, method="vavg")
+    assert np.max(np.abs(full - ref) / np.maximum(np.abs(ref), 1.0)) <= 1e-4
+    rows = []
+    for mp in (1, 2, 3):
+        cols = []
+        for sp in (1, 2):
+            tdr = TrialDataReader("scp:vectors.scp", "trials.ndx", "enroll.lst", model_part_idx=mp,
+                                  num_model_parts=3, seg_part_idx=sp, num_seg_parts=2)
+            xe, xt, inf, nd = tdr.read_device()
+            idp = np.unique(inf, return_inverse=True)[1]
+            blk = plda.llr_Nvs1(tl.predict(xe), tl.predict(xt), ids1=idp, method="vavg").cpu().numpy()
+            assert blk.shape == nd.trial_mask.shape
+            cols.append(blk)
+        rows.append(np.hstack(cols))
+    assert np.allclose(np.vstack(rows), full, rtol=0, atol=2e-5 * np.abs(full).max())
