@@ -5,7 +5,7 @@
 
 One "step" = one pass of the hot path over one batch of synthetic x-vectors that are already
 resident in HBM: embedding prologue (pre-processing chain + PLDA projection) for the enrol and the
-test side, conversion of the packed rows to three-way bf16 splits, then the full trial score matrix
+test side, conversion of the packed rows to scaled fp16 pairs, then the full trial score matrix
 (kept on the device).  With N > 1 every rank scores the
 same enrol set against its own shard of test vectors (row-wise test sharding, no data-path
 collective): per-GPU work is fixed, so scaling is "weak" and the reported value is the number of
@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=20000,
                     help="rows/cols of the square slice the CPU baseline is timed on")
+    ap.add_argument("--split-format", default="pair", choices=["pair", "triple", "none"],
+                    help="operands of the score kernel: scaled fp16 pairs, exact bf16 triples, or fp32")
     ap.add_argument("--no-asnorm-stage", action="store_true",
                     help="skip the extra AS-norm stage measurement of the default workload")
     return ap.parse_args()
@@ -262,7 +264,9 @@ def main():
 
     ev_pairs, ev_pro = [], []
 
-    use_split = engine.split_rows(plan.prologue(x1[:1], SIDE_ENROL)) is not None
+    fmt = args.split_format
+    use_split = fmt != "none" and engine.split_rows(plan.prologue(x1[:1], SIDE_ENROL), fmt) is not None
+    products = {"pair": 3, "triple": 6}.get(fmt, 1)
 
     def step(record):
         if record:
@@ -270,8 +274,8 @@ def main():
             p0.record()
         G1 = plan.prologue(x1, SIDE_ENROL)
         G2 = plan.prologue(x2, SIDE_TEST)
-        if use_split:  # bf16 matrix cores at fp32 accuracy
-            G1, G2 = engine.split_rows(G1), engine.split_rows(G2)
+        if use_split:  # 16-bit matrix cores at fp32 accuracy
+            G1, G2 = engine.split_rows(G1, fmt), engine.split_rows(G2, fmt)
         if record:
             p1.record()
             ev_pro.append((p0, p1))
@@ -312,8 +316,9 @@ def main():
     value = scores_per_step * args.steps / dt
     K = cfg["K"]
     achieved_tflops = 2.0 * K * n1 * n2 / (score_ms * 1e-3) / 1e12
-    # the split kernel executes 6 bf16 partial products per fp32 product over the K + 2 packed columns
-    executed_tflops = 6 * 2.0 * (K + 2) * n1 * n2 / (score_ms * 1e-3) / 1e12
+    # the split kernels execute 3 (fp16 pairs) or 6 (bf16 triples) partial products per fp32 product
+    # over the K + 2 packed columns
+    executed_tflops = products * 2.0 * (K + 2) * n1 * n2 / (score_ms * 1e-3) / 1e12
 
     out = {
         "metric": "PLDA trial scores/sec (512-d, SPLDA)",
@@ -336,7 +341,7 @@ def main():
             "parallelism": "test rows sharded over %d GPU(s), enrol replicated" % world,
         },
         "roofline": {
-            "kernel": ("score_split_kernel<%d>" % ((plan.kp + 31) // 32)) if use_split
+            "kernel": ("score_split_kernel<%d,%d>" % (2 if fmt == "pair" else 3, (plan.kp + 31) // 32)) if use_split
                       else "score_rs_kernel<%d,2>" % plan.kp,
             "bound": "mfma",
             "achieved": achieved_tflops,
@@ -347,20 +352,23 @@ def main():
             "avg_launch_ms": score_ms,
             "algorithmic_flops_per_launch": 2.0 * K * n1 * n2,
             "note": "algorithmic fp32 flops (2 K per score) against the fp32 matrix peak; above 1 because "
-                    "the products run on the bf16 matrix cores as exact three-way splits" if use_split
+                    "the products run on the 16-bit matrix cores (%s)" % (
+                        "scaled fp16 pairs, 3 partial products" if fmt == "pair" else
+                        "exact bf16 triples, 6 partial products") if use_split
                     else "fp32 matrix cores",
             "hbm_store_GBs": 4.0 * n1 * n2 / (score_ms * 1e-3) / 1e9,
         },
     }
     out["prologue_stage"] = {
-        "what": "pre-processing chain + PLDA projection + packing (+ bf16 split) of %d + %d vectors" % (n1, n2),
+        "what": "pre-processing chain + PLDA projection + packing (+ 16-bit split) of %d + %d vectors" % (n1, n2),
         "ms": pro_ms, "bound": "hbm", "achieved": pro_bytes / (pro_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": pro_bytes / (pro_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "algorithmic_bytes": pro_bytes,
         "note": "matrix-core bound in practice (2 x 512 x 350 flop per vector on the fp32 MFMA)"}
     if use_split:
         out["roofline"]["executed"] = {
-            "pipe": "bf16 MFMA (6 partial products per fp32 product, K + 2 packed columns)",
+            "pipe": "%s MFMA (%d partial products per fp32 product, K + 2 packed columns)"
+                    % ("fp16" if fmt == "pair" else "bf16", products),
             "achieved": executed_tflops, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": executed_tflops / BF16_MFMA_PEAK_TFLOPS}
 

@@ -79,6 +79,11 @@ SIGNATURES = {
     "hypmi_split_rows": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, c_void_p, c_void_p]),
     "hypmi_score_split": (ctypes.c_int, [c_void_p, i64, c_void_p, i64, ctypes.c_int, c_void_p, i64,
                                          c_void_p]),
+    "hypmi_pair_row_bytes": (i64, [ctypes.c_int]),
+    "hypmi_pair_bytes": (i64, [ctypes.c_int, i64]),
+    "hypmi_pair_rows": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, c_void_p, c_void_p]),
+    "hypmi_score_pair": (ctypes.c_int, [c_void_p, i64, c_void_p, i64, ctypes.c_int, c_void_p, i64,
+                                         c_void_p]),
     "hypmi_affine": (ctypes.c_int, [c_void_p, i64, i64, ctypes.c_int, c_void_p, i64, c_void_p,
                                     ctypes.c_int, c_void_p, i64, c_void_p]),
     "hypmi_lnorm_rows": (ctypes.c_int, [c_void_p, i64, i64, ctypes.c_int, c_void_p]),

@@ -1,5 +1,6 @@
-// Trial score matrix on the gfx950 bf16 matrix cores at fp32 accuracy.
+// Trial score matrix on the gfx950 16-bit matrix cores at fp32 accuracy, in two operand formats.
 //
+// (1) bf16 triples, exact:
 // Every fp32 value of a packed row is written as the exact sum of three bf16 numbers
 // x = x0 + x1 + x2 (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1); 3 x 8 significand bits
 // plus the signs of the residuals cover the 24 bits of an fp32).  The inner product of two rows is
@@ -11,14 +12,25 @@
 // arithmetic throughput of the fp32 kernel in score.hip at the same accuracy.  The three magnitude
 // classes are accumulated separately and added once per tile, smallest first.
 //
-// Split rows (hypmi_split_rows): coordinates are handled in chunks of 8 (one 16-byte slot = 8 bf16
-// of one part).  With KS16 = 2 * ceil(KP / 32) chunk pairs, a row is
-//     [ HS slots: even chunks ][ 3 * KS16 slots: odd chunks ][ pad to an odd slot count ]
-// where HS = 3 * KS16 rounded up to 16 and slot 3 * j + s of a half holds part s of chunk 2 * j + h
+// (2) fp16 pairs, scaled (the default path): every row is multiplied by a power of two that puts its
+// largest magnitude in [2^14, 2^15) and each scaled value is written as x0 + x1 with x0 = fp16(x),
+// x1 = fp16(x - x0): 2 x 11 significand bits plus the sign of the residual, |x - x0 - x1| <= 2^-22 |x|
+// (and <= 2^-28 of the row maximum where x1 leaves the normal fp16 range).  Three products
+//     x y  ~=  x0 y0  +  (x0 y1 + x1 y0)
+// are accumulated in fp32 by v_mfma_f32_16x16x32_f16 (fp16 x fp16 is exact in fp32) in two classes;
+// the dropped x1 y1 is <= 2^-22 |x y|.  Measured against float64 the result is closer than an fp32
+// product chain over the same rows (fewer roundings of partial sums), at half the matrix
+// instructions and two thirds of the operand traffic of format (1).  The inverse scale of a row
+// travels in the last (padding) slot of its split row and is applied when a tile is summed.
+//
+// Split rows (hypmi_split_rows, hypmi_pair_rows): coordinates are handled in chunks of 8 (one
+// 16-byte slot = 8 values of one part).  With NP parts and KS16 = 2 * ceil(KP / 32) chunk pairs, a row is
+//     [ HS slots: even chunks ][ NP * KS16 slots: odd chunks ][ pad to an odd slot count ]
+// where HS = NP * KS16 rounded up to 16 and slot NP * j + s of a half holds part s of chunk 2 * j + h
 // (coordinates 16 * j + 8 * h .. + 7).  v_mfma_f32_16x16x32_bf16 takes chunk `lane >> 4` of a k-step
 // of 32 from every lane, so the lanes of one ds_read_b128 bank group read either the same slot
 // offset or offsets HS apart: with HS a multiple of 16 slots and an odd row pitch all 16 lanes of a
-// group land on different 16-byte bank slots.  1008 bytes per row at K = 150.
+// group land on different 16-byte bank slots.  At K = 150: 1008 bytes per row of triples, 848 of pairs.
 //
 // The kernel has the structure of score_rs_kernel: the split rows of 32 enrol vectors stay in
 // registers for the life of a wave (2 row tiles of 16), test rows stream through two LDS buffers by
@@ -32,6 +44,25 @@
 namespace hypmi_detail {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// Operand type and matrix instruction of a format, by its number of parts.
+template <int NP>
+struct SplitFmt;
+template <>
+struct SplitFmt<3> {
+    typedef bf16x8 vec;
+    static __device__ __forceinline__ f32x4 mfma(vec a, vec b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <>
+struct SplitFmt<2> {
+    typedef f16x8 vec;
+    static __device__ __forceinline__ f32x4 mfma(vec a, vec b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
 
 __device__ __forceinline__ unsigned bf16_rn_bits(float x) {
     const unsigned u = __float_as_uint(x);
@@ -56,8 +87,11 @@ __device__ __forceinline__ void split3(float x, unsigned& b0, unsigned& b1, unsi
     b2 = bf16_rn_bits(r2);
 }
 
-__host__ __device__ constexpr int split_half_slots(int ks16) { return (3 * ks16 + 15) / 16 * 16; }
-__host__ __device__ constexpr int split_row_slots(int ks16) { return (split_half_slots(ks16) + 3 * ks16) | 1; }
+__host__ __device__ constexpr int split_half_slots(int ks16, int np = 3) { return (np * ks16 + 15) / 16 * 16; }
+// the sum of the two halves is even, so the last slot of a row is always padding
+__host__ __device__ constexpr int split_row_slots(int ks16, int np = 3) {
+    return (split_half_slots(ks16, np) + np * ks16) | 1;
+}
 
 // One thread per (row, chunk pair, half): 8 coordinates -> 3 slots; the first thread of a row also
 // clears the padding slots.
@@ -100,6 +134,67 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     }
 }
 
+// fp16 pairs: one wavefront per row (lane = chunk of 8 coordinates, kp <= 512).  The row maximum
+// (finite values only) fixes the power of two; the last slot of the row keeps the inverse scale.
+__global__ __launch_bounds__(256) void pair_rows_kernel(const float* __restrict__ G, int64_t n, int kp,
+                                                        int ks16, uint4* __restrict__ H) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int k0 = 8 * lane;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (k0 < kp) {  // kp is a multiple of 8: all eight or none
+        const float* src = G + row * kp + k0;
+        const float4 lo = *reinterpret_cast<const float4*>(src);
+        const float4 hi = *reinterpret_cast<const float4*>(src + 4);
+        v[0] = lo.x, v[1] = lo.y, v[2] = lo.z, v[3] = lo.w;
+        v[4] = hi.x, v[5] = hi.y, v[6] = hi.z, v[7] = hi.w;
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float a = fabsf(v[e]);
+        if (a <= 3.402823466e38f && a > m) m = a;  // NaN and infinity do not set the scale
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    // m = f * 2^ex with f in [0.5, 1): scaling by 2^(15 - ex) puts the maximum in [2^14, 2^15); capped
+    // so that the inverse scale 2^-up stays a normal float (rows below 2^-111 keep fewer bits)
+    int up = m > 0.f ? 15 - __builtin_amdgcn_frexp_expf(m) : 0;
+    if (up > 126) up = 126;
+    const int hs = split_half_slots(ks16, 2), row_slots = split_row_slots(ks16, 2);
+    uint4* out = H + row * row_slots;
+    if (k0 < 16 * ks16) {
+        unsigned b[2][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = ldexpf(v[e], up);
+            const _Float16 x0 = (_Float16)x;  // round to nearest even; NaN and infinity keep their class
+            const float r = x - (float)x0;
+            const _Float16 x1 = (r == r && fabsf(r) <= 3.402823466e38f) ? (_Float16)r : (_Float16)0.f;
+            b[0][e] = __builtin_bit_cast(unsigned short, x0);
+            b[1][e] = __builtin_bit_cast(unsigned short, x1);
+        }
+        const int j = lane >> 1, h = lane & 1;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint4 w;
+            w.x = b[s][0] | (b[s][1] << 16);
+            w.y = b[s][2] | (b[s][3] << 16);
+            w.z = b[s][4] | (b[s][5] << 16);
+            w.w = b[s][6] | (b[s][7] << 16);
+            out[h * hs + 2 * j + s] = w;
+        }
+    }
+    if (lane == 0) {
+        for (int p = 2 * ks16; p < hs; ++p) out[p] = make_uint4(0, 0, 0, 0);
+        for (int p = hs + 2 * ks16; p < row_slots - 1; ++p) out[p] = make_uint4(0, 0, 0, 0);
+        out[row_slots - 1] = make_uint4(__float_as_uint(ldexpf(1.f, -up)), 0, 0, 0);
+    }
+}
+
 // LDS-DMA piece with a wave-uniform source: lane copies the 16 bytes at sbase + voff to LDS address
 // lds_dst + 16 * lane (no per-lane address arithmetic; see lds_dma_16 for why it is inline asm).
 __device__ __forceinline__ void lds_dma_16_uniform(const void* sbase, unsigned voff, unsigned lds_dst) {
@@ -119,16 +214,19 @@ __device__ __forceinline__ void lds_dma_16_uniform(const void* sbase, unsigned v
 // (stage, multiply, guarded stores).
 // Up to 160 coordinates (KS2 <= 5) a wave needs fewer than 256 registers and two workgroups share a
 // CU; wider rows keep up to 240 registers of stationary operand alone and run one wave per SIMD.
-template <int KS2>  // k-steps of 32 coordinates
-__global__ __launch_bounds__(256, (KS2 <= 5 ? 2 : 1)) void score_split_kernel(const uint4* __restrict__ H1,
+// Pairs hold two thirds of that per row: two workgroups per CU up to KS2 = 7.
+template <int NP, int KS2>  // parts per value; k-steps of 32 coordinates
+__global__ __launch_bounds__(256, (KS2 <= (NP == 3 ? 5 : 7) ? 2 : 1)) void score_split_kernel(const uint4* __restrict__ H1,
                                                              const uint4* __restrict__ H2,
                                                              float* __restrict__ S, int64_t n1,
                                                              int64_t n2, int64_t ldo,
                                                              int tiles_per_chunk) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    typedef SplitFmt<NP> Fmt;
+    typedef typename Fmt::vec vec_t;
     constexpr int KS16 = 2 * KS2;
-    constexpr int HS = split_half_slots(KS16);
-    constexpr int ROW_SLOTS = split_row_slots(KS16);
+    constexpr int HS = split_half_slots(KS16, NP);
+    constexpr int ROW_SLOTS = split_row_slots(KS16, NP);
     constexpr int TILE_SLOTS = 32 * ROW_SLOTS;
     constexpr int PIECES = (TILE_SLOTS + 63) / 64;  // LDS-DMA instructions per tile
     constexpr int BUF_SLOTS = PIECES * 64;          // the last piece runs past the tile (see hypmi_split_bytes)
@@ -138,11 +236,11 @@ __global__ __launch_bounds__(256, (KS2 <= 5 ? 2 : 1)) void score_split_kernel(co
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
-    const int my_slot = (kq & 1) * HS + 3 * (kq >> 1);  // + 6 * ks + s
+    const int my_slot = (kq & 1) * HS + NP * (kq >> 1);  // + 2 * NP * ks + s
     const int64_t i0 = (int64_t)blockIdx.x * 128 + wave * 32;
 
     // stationary operand: a[rt][s][ks] = part s of H1[i0 + 16 rt + r16], coordinates 32 ks + 8 kq .. + 7
-    bf16x8 a[2][3][KS2];
+    vec_t a[2][NP][KS2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         int64_t row = i0 + 16 * rt + r16;
@@ -151,8 +249,22 @@ __global__ __launch_bounds__(256, (KS2 <= 5 ? 2 : 1)) void score_split_kernel(co
 #pragma unroll
         for (int ks = 0; ks < KS2; ++ks)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) a[rt][s][ks] = __builtin_bit_cast(bf16x8, p[6 * ks + s]);
+            for (int s = 0; s < NP; ++s) a[rt][s][ks] = __builtin_bit_cast(vec_t, p[2 * NP * ks + s]);
     }
+    // pairs: inverse scales of the eight enrol rows whose scores this lane holds after the MFMAs
+    // (row 16 rt + 4 (lane >> 4) + e of the wave's block)
+    float rs[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            rs[rt][e] = 1.f;
+            if constexpr (NP == 2) {
+                int64_t row = i0 + 16 * rt + 4 * kq + e;
+                if (row > n1 - 1) row = n1 - 1;
+                rs[rt][e] = __uint_as_float(H1[row * ROW_SLOTS + ROW_SLOTS - 1].x);
+            }
+        }
 
     const int64_t tile0 = (int64_t)blockIdx.y * tiles_per_chunk;
     const int64_t ntiles_all = (n2 + 31) / 32;
@@ -181,7 +293,7 @@ __global__ __launch_bounds__(256, (KS2 <= 5 ? 2 : 1)) void score_split_kernel(co
     auto run = [&](auto steady_tag) {
         constexpr bool ST = decltype(steady_tag)::value;
         constexpr int NSIDE = ST ? NPW + 16 : 0;  // DMA pieces, then stores, between the MFMA groups
-        constexpr int NSLOT = 6 * KS2;
+        constexpr int NSLOT = 2 * NP * KS2;
 
         auto stage_piece = [&](int it, int buf, int p) {
             const int q = 4 * p + wave;
@@ -225,7 +337,7 @@ __global__ __launch_bounds__(256, (KS2 <= 5 ? 2 : 1)) void score_split_kernel(co
             __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 s_rows + (tile0 + it - 1) * 32, 0, it > 0 ? span : 0u, 0x00020000);
 
-            f32x4 hi[2][2], mid[2][2], lo[2][2];
+            f32x4 hi[2][2], mid[2][2], lo[2][2];  // pairs use hi and lo only
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -233,11 +345,18 @@ __global__ __launch_bounds__(256, (KS2 <= 5 ? 2 : 1)) void score_split_kernel(co
 #pragma unroll
                     for (int e = 0; e < 4; ++e) hi[rt][ct][e] = mid[rt][ct][e] = lo[rt][ct][e] = 0.f;
 
-            // bt[(16 ct) * ROW_SLOTS + 6 ks + s]: part s of test row 16 ct + r16, this lane's chunk of k-step ks
+            // bt[(16 ct) * ROW_SLOTS + 2 NP ks + s]: part s of test row 16 ct + r16, this lane's chunk of k-step ks
             const uint4* bt = tile + buf * BUF_SLOTS + r16 * ROW_SLOTS + my_slot;
-            bf16x8 b[3];
+            vec_t b[NP];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) b[s] = __builtin_bit_cast(bf16x8, bt[s]);
+            for (int s = 0; s < NP; ++s) b[s] = __builtin_bit_cast(vec_t, bt[s]);
+            // pairs: inverse scales of this lane's two columns (test rows r16 and 16 + r16 of the tile)
+            float cs[2] = {1.f, 1.f};
+            if constexpr (NP == 2) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    cs[ct] = __uint_as_float(tile[buf * BUF_SLOTS + (16 * ct + r16) * ROW_SLOTS + ROW_SLOTS - 1].x);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < KS2; ++ks) {
@@ -245,25 +364,34 @@ __global__ __launch_bounds__(256, (KS2 <= 5 ? 2 : 1)) void score_split_kernel(co
                 for (int ct = 0; ct < 2; ++ct) {
                     // operands of the next half step: the other column tile, or the next k-step
                     const int nct = ct ^ 1, nks = ct ? (ks + 1 < KS2 ? ks + 1 : ks) : ks;
-                    bf16x8 nb[3];
+                    vec_t nb[NP];
 #pragma unroll
-                    for (int g = 0; g < 3; ++g) {
-                        nb[g] = __builtin_bit_cast(bf16x8, bt[16 * nct * ROW_SLOTS + 6 * nks + g]);
+                    for (int g = 0; g < NP; ++g) {
+                        nb[g] = __builtin_bit_cast(vec_t, bt[16 * nct * ROW_SLOTS + 2 * NP * nks + g]);
 #pragma unroll
                         for (int rt = 0; rt < 2; ++rt) {
-                            if (g == 0) {
-                                mid[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][1][ks], b[0], mid[rt][ct], 0, 0, 0);
-                                lo[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][2][ks], b[0], lo[rt][ct], 0, 0, 0);
-                            } else if (g == 1) {
-                                hi[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][0][ks], b[0], hi[rt][ct], 0, 0, 0);
-                                lo[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][1][ks], b[1], lo[rt][ct], 0, 0, 0);
+                            if constexpr (NP == 3) {
+                                if (g == 0) {
+                                    mid[rt][ct] = Fmt::mfma(a[rt][1][ks], b[0], mid[rt][ct]);
+                                    lo[rt][ct] = Fmt::mfma(a[rt][2][ks], b[0], lo[rt][ct]);
+                                } else if (g == 1) {
+                                    hi[rt][ct] = Fmt::mfma(a[rt][0][ks], b[0], hi[rt][ct]);
+                                    lo[rt][ct] = Fmt::mfma(a[rt][1][ks], b[1], lo[rt][ct]);
+                                } else {
+                                    mid[rt][ct] = Fmt::mfma(a[rt][0][ks], b[1], mid[rt][ct]);
+                                    lo[rt][ct] = Fmt::mfma(a[rt][0][ks], b[2], lo[rt][ct]);
+                                }
                             } else {
-                                mid[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][0][ks], b[1], mid[rt][ct], 0, 0, 0);
-                                lo[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][0][ks], b[2], lo[rt][ct], 0, 0, 0);
+                                if (g == 0) {
+                                    lo[rt][ct] = Fmt::mfma(a[rt][1][ks], b[0], lo[rt][ct]);
+                                    hi[rt][ct] = Fmt::mfma(a[rt][0][ks], b[0], hi[rt][ct]);
+                                } else {
+                                    lo[rt][ct] = Fmt::mfma(a[rt][0][ks], b[1], lo[rt][ct]);
+                                }
                             }
                         }
                         // side work of this slot
-                        const int j = (2 * ks + ct) * 3 + g;
+                        const int j = (2 * ks + ct) * NP + g;
 #pragma unroll
                         for (int idx = j * NSIDE / NSLOT; idx < (j + 1) * NSIDE / NSLOT; ++idx) {
                             if (idx < NPW) {
@@ -277,15 +405,26 @@ __global__ __launch_bounds__(256, (KS2 <= 5 ? 2 : 1)) void score_split_kernel(co
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
-                    for (int s = 0; s < 3; ++s) b[s] = nb[s];
+                    for (int s = 0; s < NP; ++s) b[s] = nb[s];
                 }
             }
-            // three-way sum, then the two column tiles of a row side by side:
+            // sum of the classes (and un-scaling), then the two column tiles of a row side by side:
             // X' = [X.q0 Y.q0 X.q2 Y.q2], Y' = [X.q1 Y.q1 X.q3 Y.q3]  (q = 16-lane group = 4 rows)
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
-                const f32x4 x = hi[rt][0] + (mid[rt][0] + lo[rt][0]);
-                const f32x4 y = hi[rt][1] + (mid[rt][1] + lo[rt][1]);
+                f32x4 x, y;
+                if constexpr (NP == 3) {
+                    x = hi[rt][0] + (mid[rt][0] + lo[rt][0]);
+                    y = hi[rt][1] + (mid[rt][1] + lo[rt][1]);
+                } else {
+                    x = hi[rt][0] + lo[rt][0];
+                    y = hi[rt][1] + lo[rt][1];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x[e] = (x[e] * rs[rt][e]) * cs[0];
+                        y[e] = (y[e] * rs[rt][e]) * cs[1];
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[e]), __float_as_uint(y[e]),
@@ -320,19 +459,19 @@ __global__ __launch_bounds__(256, (KS2 <= 5 ? 2 : 1)) void score_split_kernel(co
 #endif
 }
 
-template <int KS2>
+template <int NP, int KS2>
 static int launch_split(const uint4* H1, int64_t n1, const uint4* H2, int64_t n2, float* S, int64_t lds,
                         hipStream_t stream) {
-    constexpr int PIECES = (32 * split_row_slots(2 * KS2) + 63) / 64;
+    constexpr int PIECES = (32 * split_row_slots(2 * KS2, NP) + 63) / 64;
     constexpr int LDS_BYTES = 2 * PIECES * 64 * 16;
     static_assert(LDS_BYTES <= 160 * 1024, "tile buffers exceed the LDS");
     LaunchGeom g;
     int rc = launch_geometry(n1, n2, 128, &g);
     if (rc != HYPMI_OK) return rc;
     if (LDS_BYTES > 48 * 1024)
-        HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_split_kernel<KS2>),
+        HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_split_kernel<NP, KS2>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    hipLaunchKernelGGL((score_split_kernel<KS2>), dim3((unsigned)g.gx, (unsigned)g.gy), dim3(256), LDS_BYTES,
+    hipLaunchKernelGGL((score_split_kernel<NP, KS2>), dim3((unsigned)g.gx, (unsigned)g.gy), dim3(256), LDS_BYTES,
                        stream, H1, H2, S, n1, n2, lds, g.tiles_per_chunk);
     HYPMI_HIP(hipGetLastError());
     return HYPMI_OK;
@@ -351,58 +490,82 @@ static int split_ksteps(int kp) {
     return ks2 <= SPLIT_MAX_KS2 ? ks2 : 0;
 }
 
-extern "C" int64_t hypmi_split_row_bytes(int kp) {
+namespace {
+
+int64_t row_bytes_of(int kp, int np) {
     const int ks2 = split_ksteps(kp);
-    return ks2 ? (int64_t)split_row_slots(2 * ks2) * 16 : 0;
+    return ks2 ? (int64_t)split_row_slots(2 * ks2, np) * 16 : 0;
 }
 
 // n rows plus 1 KiB: the last LDS-DMA piece of a tile copies up to 63 slots beyond it
-extern "C" int64_t hypmi_split_bytes(int kp, int64_t n) {
-    const int64_t rb = hypmi_split_row_bytes(kp);
+int64_t buffer_bytes_of(int kp, int np, int64_t n) {
+    const int64_t rb = row_bytes_of(kp, np);
     return (rb && n >= 0) ? n * rb + 1024 : 0;
 }
 
-extern "C" int hypmi_split_rows(const float* G, int64_t n, int kp, void* H, void* stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+int convert_rows(const char* what, int np, const float* G, int64_t n, int kp, void* H, hipStream_t stream) {
     const int ks = 2 * split_ksteps(kp);  // chunk pairs
-    HYPMI_REQUIRE(ks > 0, "split_rows: no split kernel for packed width %d", kp);
-    HYPMI_REQUIRE(n >= 0, "split_rows: bad row count");
+    HYPMI_REQUIRE(ks > 0, "%s: no split kernel for packed width %d", what, kp);
+    HYPMI_REQUIRE(n >= 0, "%s: bad row count", what);
     if (n == 0) return HYPMI_OK;
-    HYPMI_REQUIRE(G && H, "split_rows: null pointer");
-    HYPMI_REQUIRE(aligned16(G) && aligned16(H), "split_rows: buffers must be 16-byte aligned");
-    const int64_t threads = n * 2 * ks;
-    const int64_t blocks = (threads + 255) / 256;
-    HYPMI_REQUIRE(blocks <= 0x7fffffffLL, "split_rows: too many rows");
-    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, G, n, kp, ks,
-                       static_cast<uint4*>(H));
+    HYPMI_REQUIRE(G && H, "%s: null pointer", what);
+    HYPMI_REQUIRE(aligned16(G) && aligned16(H), "%s: buffers must be 16-byte aligned", what);
+    const int64_t blocks = np == 3 ? (n * 2 * ks + 255) / 256 : (n + 3) / 4;
+    HYPMI_REQUIRE(blocks <= 0x7fffffffLL, "%s: too many rows", what);
+    if (np == 3)
+        hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, G, n, kp, ks,
+                           static_cast<uint4*>(H));
+    else
+        hipLaunchKernelGGL(pair_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, G, n, kp, ks,
+                           static_cast<uint4*>(H));
     HYPMI_HIP(hipGetLastError());
     return HYPMI_OK;
 }
 
-extern "C" int hypmi_score_split(const void* H1_, int64_t n1, const void* H2_, int64_t n2, int kp,
-                                 float* S, int64_t lds, void* stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+template <int NP>
+int score_rows(const char* what, const void* H1_, int64_t n1, const void* H2_, int64_t n2, int kp, float* S,
+               int64_t lds, hipStream_t stream) {
     const int ks = split_ksteps(kp);
-    HYPMI_REQUIRE(ks > 0, "score_split: no split kernel for packed width %d", kp);
-    HYPMI_REQUIRE(n1 >= 0 && n2 >= 0, "score_split: bad shape n1=%lld n2=%lld", (long long)n1,
-                  (long long)n2);
-    HYPMI_REQUIRE(lds >= n2, "score_split: output leading dimension %lld < n2 %lld", (long long)lds,
-                  (long long)n2);
+    HYPMI_REQUIRE(ks > 0, "%s: no split kernel for packed width %d", what, kp);
+    HYPMI_REQUIRE(n1 >= 0 && n2 >= 0, "%s: bad shape n1=%lld n2=%lld", what, (long long)n1, (long long)n2);
+    HYPMI_REQUIRE(lds >= n2, "%s: output leading dimension %lld < n2 %lld", what, (long long)lds, (long long)n2);
     if (n1 == 0 || n2 == 0) return HYPMI_OK;
-    HYPMI_REQUIRE(H1_ && H2_ && S, "score_split: null pointer");
-    HYPMI_REQUIRE(aligned16(H1_) && aligned16(H2_), "score_split: split rows must be 16-byte aligned");
+    HYPMI_REQUIRE(H1_ && H2_ && S, "%s: null pointer", what);
+    HYPMI_REQUIRE(aligned16(H1_) && aligned16(H2_), "%s: split rows must be 16-byte aligned", what);
     const uint4* H1 = static_cast<const uint4*>(H1_);
     const uint4* H2 = static_cast<const uint4*>(H2_);
     switch (ks) {
-        case 1: return launch_split<1>(H1, n1, H2, n2, S, lds, stream);
-        case 2: return launch_split<2>(H1, n1, H2, n2, S, lds, stream);
-        case 3: return launch_split<3>(H1, n1, H2, n2, S, lds, stream);
-        case 4: return launch_split<4>(H1, n1, H2, n2, S, lds, stream);
-        case 5: return launch_split<5>(H1, n1, H2, n2, S, lds, stream);
-        case 6: return launch_split<6>(H1, n1, H2, n2, S, lds, stream);
-        case 7: return launch_split<7>(H1, n1, H2, n2, S, lds, stream);
-        case 8: return launch_split<8>(H1, n1, H2, n2, S, lds, stream);
-        case 9: return launch_split<9>(H1, n1, H2, n2, S, lds, stream);
-        default: return launch_split<10>(H1, n1, H2, n2, S, lds, stream);
+        case 1: return launch_split<NP, 1>(H1, n1, H2, n2, S, lds, stream);
+        case 2: return launch_split<NP, 2>(H1, n1, H2, n2, S, lds, stream);
+        case 3: return launch_split<NP, 3>(H1, n1, H2, n2, S, lds, stream);
+        case 4: return launch_split<NP, 4>(H1, n1, H2, n2, S, lds, stream);
+        case 5: return launch_split<NP, 5>(H1, n1, H2, n2, S, lds, stream);
+        case 6: return launch_split<NP, 6>(H1, n1, H2, n2, S, lds, stream);
+        case 7: return launch_split<NP, 7>(H1, n1, H2, n2, S, lds, stream);
+        case 8: return launch_split<NP, 8>(H1, n1, H2, n2, S, lds, stream);
+        case 9: return launch_split<NP, 9>(H1, n1, H2, n2, S, lds, stream);
+        default: return launch_split<NP, 10>(H1, n1, H2, n2, S, lds, stream);
     }
+}
+
+}  // namespace
+
+extern "C" int64_t hypmi_split_row_bytes(int kp) { return row_bytes_of(kp, 3); }
+extern "C" int64_t hypmi_split_bytes(int kp, int64_t n) { return buffer_bytes_of(kp, 3, n); }
+extern "C" int hypmi_split_rows(const float* G, int64_t n, int kp, void* H, void* stream) {
+    return convert_rows("split_rows", 3, G, n, kp, H, static_cast<hipStream_t>(stream));
+}
+extern "C" int hypmi_score_split(const void* H1, int64_t n1, const void* H2, int64_t n2, int kp, float* S,
+                                 int64_t lds, void* stream) {
+    return score_rows<3>("score_split", H1, n1, H2, n2, kp, S, lds, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int64_t hypmi_pair_row_bytes(int kp) { return row_bytes_of(kp, 2); }
+extern "C" int64_t hypmi_pair_bytes(int kp, int64_t n) { return buffer_bytes_of(kp, 2, n); }
+extern "C" int hypmi_pair_rows(const float* G, int64_t n, int kp, void* H, void* stream) {
+    return convert_rows("pair_rows", 2, G, n, kp, H, static_cast<hipStream_t>(stream));
+}
+extern "C" int hypmi_score_pair(const void* H1, int64_t n1, const void* H2, int64_t n2, int kp, float* S,
+                                int64_t lds, void* stream) {
+    return score_rows<2>("score_pair", H1, n1, H2, n2, kp, S, lds, static_cast<hipStream_t>(stream));
 }

@@ -211,11 +211,19 @@ class Plan:
         return y[:, :self.d_out]
 
 
-class SplitRows:
-    """Packed rows in the three-way bf16 split format of the bf16 score kernel."""
+# Operand formats of the 16-bit matrix-core score kernels: C entry points by format name.
+SPLIT_FORMATS = {
+    "pair": ("hypmi_pair_row_bytes", "hypmi_pair_bytes", "hypmi_pair_rows", "hypmi_score_pair"),
+    "triple": ("hypmi_split_row_bytes", "hypmi_split_bytes", "hypmi_split_rows", "hypmi_score_split"),
+}
+DEFAULT_SPLIT = "pair"  # scaled fp16 pairs; "triple": exact bf16 triples
 
-    def __init__(self, H, n, kp):
-        self.H, self.n, self.kp = H, n, kp
+
+class SplitRows:
+    """Packed rows converted for a 16-bit matrix-core score kernel (fmt: "pair" or "triple")."""
+
+    def __init__(self, H, n, kp, fmt):
+        self.H, self.n, self.kp, self.fmt = H, n, kp, fmt
 
     @property
     def shape(self):
@@ -226,44 +234,48 @@ class SplitRows:
         return self.H.device
 
 
-def split_rows(G):
+def split_rows(G, fmt=None):
     """Packed fp32 rows [n, kp] -> SplitRows, or None when kp has no split kernel."""
     torch = _torch()
     lib = _lib.load()
+    fmt = fmt or DEFAULT_SPLIT
+    row_bytes_fn, bytes_fn, rows_fn, _ = SPLIT_FORMATS[fmt]
     n, kp = G.shape
-    row_bytes = lib.hypmi_split_row_bytes(kp)
-    if row_bytes == 0:
+    if getattr(lib, row_bytes_fn)(kp) == 0:
         return None
     if G.stride(1) != 1 or G.stride(0) != kp:
         G = G.contiguous()
-    H = torch.empty(lib.hypmi_split_bytes(kp, n) // 4, dtype=torch.int32, device=G.device)
+    H = torch.empty(getattr(lib, bytes_fn)(kp, n) // 4, dtype=torch.int32, device=G.device)
     if n:
-        _lib.check(lib.hypmi_split_rows(_ptr(G), n, kp, _ptr(H), stream_ptr()))
-    return SplitRows(H, n, kp)
+        _lib.check(getattr(lib, rows_fn)(_ptr(G), n, kp, _ptr(H), stream_ptr()))
+    return SplitRows(H, n, kp, fmt)
 
 
 def score(G1, G2, out=None, split=True):
     """Packed enrol rows x packed test rows -> device fp32 score matrix [n1, n2].  Either side may
-    already be SplitRows; with split=True fp32 rows are converted when their width allows it
-    (bf16 matrix cores at fp32 accuracy), otherwise the fp32 kernel runs."""
+    already be SplitRows; with split=True (or a format name) fp32 rows are converted when their
+    width allows it (16-bit matrix cores at fp32 accuracy), otherwise the fp32 kernel runs."""
     torch = _torch()
     lib = _lib.load()
     n1, kp = G1.shape
     n2, kp2 = G2.shape
     if kp != kp2:
         raise ValueError("packed widths differ: %d vs %d" % (kp, kp2))
-    pre_split = isinstance(G1, SplitRows) or isinstance(G2, SplitRows)
-    if pre_split or (split and lib.hypmi_split_row_bytes(kp) != 0 and n1 and n2):
-        H1 = G1 if isinstance(G1, SplitRows) else split_rows(G1)
-        H2 = G2 if isinstance(G2, SplitRows) else split_rows(G2)
+    given = [g.fmt for g in (G1, G2) if isinstance(g, SplitRows)]
+    fmt = given[0] if given else (split if isinstance(split, str) else DEFAULT_SPLIT)
+    if len(given) == 2 and given[0] != given[1]:
+        raise ValueError("the two sides are split in different formats: %s and %s" % tuple(given))
+    if given or (split and getattr(lib, SPLIT_FORMATS[fmt][0])(kp) != 0 and n1 and n2):
+        H1 = G1 if isinstance(G1, SplitRows) else split_rows(G1, fmt)
+        H2 = G2 if isinstance(G2, SplitRows) else split_rows(G2, fmt)
         if H1 is None or H2 is None:
             raise ValueError("packed width %d has no split kernel" % kp)
         if out is None:
             ld = round_up(max(n2, 1), 32)
             out = torch.empty((n1, ld), dtype=torch.float32, device=H1.device)[:, :n2]
         if n1 and n2:
-            _lib.check(lib.hypmi_score_split(_ptr(H1.H), n1, _ptr(H2.H), n2, kp, _ptr(out),
-                                             out.stride(0), stream_ptr()))
+            _lib.check(getattr(lib, SPLIT_FORMATS[fmt][3])(_ptr(H1.H), n1, _ptr(H2.H), n2, kp, _ptr(out),
+                                                          out.stride(0), stream_ptr()))
         return out
     if out is None:
         ld = round_up(max(n2, 1), 32)  # full 128-byte lines per stored row segment

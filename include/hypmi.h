@@ -124,6 +124,20 @@ int hypmi_split_rows(const float* G, int64_t n, int kp, void* H, void* stream);
 int hypmi_score_split(const void* H1, int64_t n1, const void* H2, int64_t n2, int kp, float* S,
                       int64_t lds, void* stream);
 
+/* The same again with fp16 PAIRS (the default path of the Python host): every row is scaled by a
+ * power of two (largest magnitude in [2^14, 2^15)) and each scaled value stored as x0 + x1 in fp16
+ * (|x - x0 - x1| <= 2^-22 |x|); three of the four partial products run on the fp16 matrix cores with
+ * fp32 accumulation and the inverse scales, kept in the padding slot of each row, are applied when
+ * a tile is summed.  Closer to float64 than an fp32 product chain on the same rows, half the matrix
+ * instructions and two thirds of the operand bytes of the bf16 triples.  Same calling sequence:
+ * hypmi_pair_row_bytes (0: no kernel for this width), hypmi_pair_bytes, hypmi_pair_rows,
+ * hypmi_score_pair.  The two formats cannot be mixed in one product. */
+int64_t hypmi_pair_row_bytes(int kp);
+int64_t hypmi_pair_bytes(int kp, int64_t n);
+int hypmi_pair_rows(const float* G, int64_t n, int kp, void* H, void* stream);
+int hypmi_score_pair(const void* H1, int64_t n1, const void* H2, int64_t n2, int kp, float* S,
+                     int64_t lds, void* stream);
+
 /* Generic y = x Wt^T + bias (one np.dot(x - mu, T) of the reference, with -mu T in bias).
  * Wt is [d_out x ldw] (the transposed weight, rows padded with zeros to ldw). */
 int hypmi_affine(const float* x, int64_t n, int64_t ldx, int d_in, const float* Wt, int64_t ldw,

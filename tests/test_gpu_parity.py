@@ -479,7 +479,7 @@ def test_split_rows_are_exact(kp):
     x = (rng.randn(n, kp) * np.exp(rng.uniform(-30, 30, size=(n, kp)))).astype(np.float32)
     x[0, :8] = [0.0, -0.0, 1.0, -1.0, 3.3895314e38, -3.4028235e38, 1e-30, -2.5e-31]
     G = torch.from_numpy(x).cuda()
-    H = engine.split_rows(G)
+    H = engine.split_rows(G, "triple")
     parts = _decode_split(H.H, n, kp)
     back = parts.sum(axis=0)[:, :kp].astype(np.float32)
     bad = np.argwhere(back != x)
@@ -493,17 +493,78 @@ def test_split_rows_are_exact(kp):
     y[1, 3] = np.inf
     y[2, 5] = np.nan
     y[3, 0] = -np.inf
-    p = _decode_split(engine.split_rows(torch.from_numpy(y).cuda()).H, 4, kp)
+    p = _decode_split(engine.split_rows(torch.from_numpy(y).cuda(), "triple").H, 4, kp)
     assert np.isposinf(p[0, 1, 3]) and np.isnan(p[0, 2, 5]) and np.isneginf(p[0, 3, 0])
     assert np.all(p[1:] == 0)
 
 
+def _decode_pair(H, n, kp):
+    """fp16 pair rows -> (parts float64 [2, n, 16 * ks16] in scaled units, inverse scale [n]).  Layout
+    as for triples with two parts per chunk; the last slot of a row holds the inverse scale."""
+    ks16 = 2 * ((kp + 31) // 32)
+    hs = (2 * ks16 + 15) // 16 * 16
+    row_slots = (hs + 2 * ks16) | 1
+    assert H.numel() == n * row_slots * 4 + 256
+    rows = H[:n * row_slots * 4].cpu().numpy().view(np.uint32).reshape(n, row_slots, 4)
+    out = np.zeros((2, n, 16 * ks16), dtype=np.float64)
+    used = np.zeros(row_slots, dtype=bool)
+    used[-1] = True
+    for j in range(ks16):
+        for s in range(2):
+            for h in range(2):
+                slot = h * hs + 2 * j + s
+                used[slot] = True
+                w = rows[:, slot, :]
+                bits = np.stack([w & 0xffff, w >> 16], axis=-1).reshape(n, 8).astype(np.uint16)
+                out[s, :, 16 * j + 8 * h:16 * j + 8 * h + 8] = bits.view(np.float16).astype(np.float64)
+    assert np.all(rows[:, ~used, :] == 0) and np.all(rows[:, -1, 1:] == 0)
+    return out, rows[:, -1, 0].copy().view(np.float32).astype(np.float64)
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("kp", [16, 64, 152, 232, 304])
+def test_pair_rows_represent_scaled_values(kp):
+    """Every row is scaled by a power of two that puts its largest magnitude in [2^14, 2^15); x0 + x1
+    is within 2^-22 of the scaled value (2^-25 absolute where the low part leaves the normal fp16
+    range); the inverse scale sits in the last slot; non-finite values keep their class and do not
+    set the scale; a row of zeros has scale one."""
+    import torch
+
+    from hyperion_amd import engine
+
+    rng = np.random.RandomState(kp)
+    n = 300
+    x = (rng.randn(n, kp) * np.exp(rng.uniform(-4, 4, size=(n, kp)))).astype(np.float32)
+    x *= np.exp2(rng.randint(-100, 100, size=(n, 1))).astype(np.float32)  # rows of very different size
+    x[0] = 0.0
+    x[1] = 0.25
+    x[1, :4] = [np.inf, -np.inf, np.nan, 1.0]
+    x[2, :] = 1e-42  # subnormal fp32
+    parts, inv = _decode_pair(engine.split_rows(torch.from_numpy(x).cuda(), "pair").H, n, kp)
+    fin = np.where(np.isfinite(x), np.abs(x), 0).max(axis=1).astype(np.float64)
+    scaled_max = fin / inv
+    big = fin > 2.0 ** -111  # below that the scale is capped so that its inverse stays a normal float
+    assert np.all((scaled_max[big] >= 2.0 ** 14) & (scaled_max[big] < 2.0 ** 15)) and inv[2] == 2.0 ** -126
+    assert inv[0] == 1.0 and np.all(np.log2(inv) == np.round(np.log2(inv)))
+    want = x.astype(np.float64) / inv[:, None]
+    got = parts.sum(axis=0)[:, :kp]
+    ok = np.isfinite(x)
+    with np.errstate(invalid="ignore"):
+        err = np.abs(got - want)
+    assert np.all(err[ok] <= np.maximum(2.0 ** -22 * np.abs(want[ok]), 2.0 ** -25))
+    assert np.all(parts[:, :, kp:] == 0)
+    assert np.isposinf(parts[0, 1, 0]) and np.isneginf(parts[0, 1, 1]) and np.isnan(parts[0, 1, 2])
+    assert np.all(parts[1, 1, :3] == 0) and got[1, 3] == 2.0 ** 14
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["pair", "triple"])
 @pytest.mark.parametrize("kp", [16, 32, 64, 96, 128, 152, 192, 232, 264, 304, 320])
 @pytest.mark.parametrize("n1,n2", [(1, 1), (31, 33), (128, 2048), (333, 2100), (700, 4133)])
-def test_split_score_matches_float64(kp, n1, n2):
-    """bf16 three-way split kernel against a float64 product of the same fp32 rows: the error stays
-    within the fp32 bound 8 * 2^-24 * sum|a b| on every entry, as does the fp32 kernel's."""
+def test_split_score_matches_float64(kp, n1, n2, fmt):
+    """Both 16-bit formats (scaled fp16 pairs, bf16 triples) against a float64 product of the same
+    fp32 rows: the error stays within the fp32 bound 8 * 2^-24 * sum|a b| on every entry, as does the
+    fp32 kernel's."""
     import torch
 
     from hyperion_amd import engine
@@ -517,7 +578,7 @@ def test_split_score_matches_float64(kp, n1, n2):
     G2[:, kp - 1] = torch.randn(n2, device="cuda", generator=g) * 500.0
     ref = (G1.double() @ G2.double().T).cpu().numpy()
     bound = (G1.double().abs() @ G2.double().abs().T).cpu().numpy() * engine.ERR_COEFF
-    S_split = engine.score(G1, G2).cpu().numpy()
+    S_split = engine.score(G1, G2, split=fmt).cpu().numpy()
     S_fp32 = engine.score(G1, G2, split=False).cpu().numpy()
     assert S_split.shape == (n1, n2)
     assert np.all(np.abs(S_split - ref) <= bound)
@@ -525,7 +586,8 @@ def test_split_score_matches_float64(kp, n1, n2):
 
 
 @pytest.mark.gpu
-def test_split_score_propagates_nan_rows():
+@pytest.mark.parametrize("fmt", ["pair", "triple"])
+def test_split_score_propagates_nan_rows(fmt):
     import torch
 
     from hyperion_amd import engine
@@ -534,12 +596,32 @@ def test_split_score_propagates_nan_rows():
     G2 = torch.randn((90, 32), device="cuda")
     G1[5, 3] = float("nan")
     G2[7, 0] = float("nan")
-    S = engine.score(G1, G2).cpu().numpy()
+    S = engine.score(G1, G2, split=fmt).cpu().numpy()
     assert np.all(np.isnan(S[5])) and np.all(np.isnan(S[:, 7]))
     mask = np.ones_like(S, dtype=bool)
     mask[5] = False
     mask[:, 7] = False
     assert np.all(np.isfinite(S[mask]))
+
+
+@pytest.mark.gpu
+def test_pair_score_rows_of_very_different_size():
+    """Per-row scaling: rows whose magnitudes differ by 2^60 (and a row of zeros) score as accurately
+    as rows of one size."""
+    import torch
+
+    from hyperion_amd import engine
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    G1 = torch.randn((257, 152), device="cuda", generator=g)
+    G2 = torch.randn((300, 152), device="cuda", generator=g)
+    G1 *= torch.exp2(torch.randint(-30, 30, (257, 1), device="cuda", generator=g).float())
+    G2 *= torch.exp2(torch.randint(-30, 30, (300, 1), device="cuda", generator=g).float())
+    G1[11] = 0.0
+    ref = (G1.double() @ G2.double().T).cpu().numpy()
+    bound = (G1.double().abs() @ G2.double().abs().T).cpu().numpy() * engine.ERR_COEFF
+    S = engine.score(G1, G2, split="pair").cpu().numpy()
+    assert np.all(np.abs(S - ref) <= bound) and np.all(S[11] == 0)
 
 
 @pytest.mark.gpu

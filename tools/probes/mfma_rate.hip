@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdint.h>
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
@@ -19,12 +20,21 @@ __device__ unsigned rnd_bf16_pair(unsigned s) {  // two bf16 in [-2, 2) with ran
     return a | (b << 16);
 }
 
+__device__ unsigned rnd_f16_pair(unsigned s) {  // two fp16 in [-2, 2) with random 10-bit mantissas
+    unsigned h = hash(s);
+    unsigned a = (h & 0x83ff) | 0x3c00, b = ((h >> 16) & 0x83ff) | 0x3c00;
+    return a | (b << 16);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void probe(float* out, int iters) {
     const unsigned tid = blockIdx.x * 256 + threadIdx.x;
     uint4 av[6], bv[6];
     for (int i = 0; i < 6; ++i) {
-        if (MODE < 2) {
+        if (MODE == 4) {
+            av[i] = make_uint4(rnd_f16_pair(tid * 97 + i), rnd_f16_pair(tid * 89 + i + 7), rnd_f16_pair(tid * 83 + i + 11), rnd_f16_pair(tid * 79 + i + 13));
+            bv[i] = make_uint4(rnd_f16_pair(tid * 73 + i), rnd_f16_pair(tid * 71 + i + 17), rnd_f16_pair(tid * 67 + i + 19), rnd_f16_pair(tid * 61 + i + 23));
+        } else if (MODE < 2) {
             av[i] = make_uint4(rnd_bf16_pair(tid * 97 + i), rnd_bf16_pair(tid * 89 + i + 7), rnd_bf16_pair(tid * 83 + i + 11), rnd_bf16_pair(tid * 79 + i + 13));
             bv[i] = make_uint4(rnd_bf16_pair(tid * 73 + i), rnd_bf16_pair(tid * 71 + i + 17), rnd_bf16_pair(tid * 67 + i + 19), rnd_bf16_pair(tid * 61 + i + 23));
         } else {
@@ -68,6 +78,19 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, int iters) {
             }
         }
         for (int e = 0; e < 16; ++e) r += (float)(c0[e] + c1[e] + c2[e]);
+    } else if (MODE == 4) {  // f16 16x16x32, 12 accumulators
+        f32x4 c[12] = {};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                c[2 * i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[i]), __builtin_bit_cast(f16x8, bv[i]), c[2 * i], 0, 0, 0);
+                c[2 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[i]), __builtin_bit_cast(f16x8, bv[5 - i]), c[2 * i + 1], 0, 0, 0);
+                if (i & 1) c[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[5 - i]), __builtin_bit_cast(f16x8, bv[i]), c[i], 0, 0, 0);
+            }
+        }
+        for (int i = 0; i < 12; ++i) for (int e = 0; e < 4; ++e) r += c[i][e];
     } else {  // i8 16x16x64
         i32x4 c[12] = {};
         for (int it = 0; it < iters; ++it) {
@@ -113,6 +136,7 @@ int main() {
     const double mk = 1e10 * 160 * 2;  // one full product over K = 160
     run<0>("bf16 32x32x16", 32768.0, 15, 6 * mk);
     run<1>("bf16 16x16x32", 16384.0, 30, 6 * mk);
+    run<4>("f16 16x16x32 x4", 16384.0, 30, 4 * mk);
     run<2>("i8 32x32x32", 65536.0, 15, 10 * mk);
     run<3>("i8 16x16x64", 32768.0, 30, 10 * mk);
     run<0>("bf16 32x32x16", 32768.0, 15, 6 * mk);

@@ -59,9 +59,10 @@ def report(name, ms, med):
 ms, med = timed(lambda: engine.score(G1, G2, out=S, split=False))
 report("fp32", ms, med)
 if lib.hypmi_split_row_bytes(a.kp):
-    S.zero_()
-    H1, H2 = engine.split_rows(G1), engine.split_rows(G2)
-    ms, med = timed(lambda: engine.score(H1, H2, out=S))
-    report("bf16x3", ms, med)
-    ms, med = timed(lambda: (engine.split_rows(G1), engine.split_rows(G2)))
-    print("split_rows of both sides: %.3f ms" % ms)
+    for fmt, label in (("triple", "bf16x3"), ("pair", "fp16x2")):
+        S.zero_()
+        H1, H2 = engine.split_rows(G1, fmt), engine.split_rows(G2, fmt)
+        ms, med = timed(lambda: engine.score(H1, H2, out=S))
+        report(label, ms, med)
+        ms, med = timed(lambda: (engine.split_rows(G1, fmt), engine.split_rows(G2, fmt)))
+        print("%s conversion of both sides: %.3f ms" % (label, ms))
