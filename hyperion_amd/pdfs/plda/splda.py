@@ -56,6 +56,26 @@ class SPLDA(PLDABase):
         return {"P": P, "row_bias": -(mu @ P), "shift_t": np.zeros(K), "shift_n": np.zeros(K),
                 "lam": lam, "c_extra": 0.0}
 
+    def project(self, T, delta_mu=None):
+        """The model of y = (x - delta_mu) T, e.g. after a PCA fitted on the recording that is being
+        diarized (hyperion/pdfs/plda/splda.py:421-431, called from
+        hyperion/diarization/diar_ahc_plda.py:131-141).  Host arithmetic on d x d matrices; this
+        object is left unchanged (the reference subtracts delta_mu from its own mu in place)."""
+        from scipy import linalg as sla
+
+        T = np.asarray(T, dtype=np.float64)
+        mu = np.asarray(self.mu, dtype=np.float64)
+        if delta_mu is not None:
+            mu = mu - np.asarray(delta_mu, dtype=np.float64)
+        W = np.asarray(self.W, dtype=np.float64)
+        if W.ndim == 1:
+            W = np.diag(W)
+        Sw = sla.cho_solve(sla.cho_factor(W), np.eye(W.shape[0]))
+        Sw_p = T.T @ Sw @ T
+        W_p = sla.cho_solve(sla.cho_factor(Sw_p), np.eye(Sw_p.shape[0]))
+        return SPLDA(mu=mu @ T, V=np.asarray(self.V, dtype=np.float64) @ T, W=0.5 * (W_p + W_p.T),
+                     fullcov_W=True)
+
     def get_config(self):
         config = {"update_W": self.update_W, "update_V": self.update_V, "fullcov_W": self.fullcov_W}
         base_config = super().get_config()

@@ -281,8 +281,28 @@ def gen_medium():
     print("medium ok")
 
 
+def gen_project():
+    """SPLDA.project + self-scoring, the diarization flow (hyperion/diarization/diar_ahc_plda.py:
+    131-143): PCA basis T and mean shift, projected model, llr_1vs1(x, x)."""
+    rng = np.random.RandomState(12)
+    m = small_models(12, 4, 5)["splda"]
+    T = np.linalg.qr(rng.randn(12, 7))[0] * np.exp(rng.uniform(-0.5, 0.5, 7))
+    delta = 0.3 * rng.randn(12)
+    r = ref_model(m).project(T, delta.copy())
+    mu, V, W = O.splda_project(m["mu"], m["V"], m["W"], T, delta)
+    close(mu, r.mu), close(V, r.V), close(W, r.W)
+    x = rng.randn(40, 7)
+    s = r.llr_1vs1(x, x)
+    close(O.llr_1vs1({"type": "splda", "mu": mu, "V": V, "W": W}, x, x), s)
+    out = dict(T=T, delta_mu=delta, p_mu=r.mu, p_V=r.V, p_W=r.W, x=x, scores=s)
+    out.update(flat("m_", m))
+    np.savez_compressed(os.path.join(OUT, "splda_project.npz"), **out)
+    print("project ok")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    gen_project()
     gen_selfcheck()
     gen_1vs1()
     gen_transforms()

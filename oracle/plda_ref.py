@@ -117,6 +117,16 @@ def splda_llr_1vs1(x1, x2, mu, V, W):
     return _llr_from_WV(x1, x2, mu, WV, VV)
 
 
+def splda_project(mu, V, W, T, delta_mu=None):
+    """SPLDA.project (hyperion/pdfs/plda/splda.py:421-431): the model of y = (x - delta_mu) T.
+    Returns (mu, V, W) of the projected model."""
+    mu = np.asarray(mu, F64)
+    if delta_mu is not None:
+        mu = mu - delta_mu
+    Sw = T.T @ (inv_pdmat(W) @ T)
+    return mu @ T, V @ T, inv_pdmat(Sw)
+
+
 def plda_aux(V, U, D):
     """hyperion/pdfs/plda/plda.py:77-89: returns (_VW [d, y_dim], _VWV [y_dim, y_dim])."""
     DV = V * D

@@ -665,3 +665,17 @@ def test_adapt_s_norm_cohort_larger_than_lds(masked):
     ref = O.adapt_s_norm(sc, ct, ec, 200, 3, **kw)
     err = np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)
     assert err.max() <= 2e-5, float(err.max())
+
+
+@pytest.mark.gpu
+def test_projected_model_self_scoring(golden):
+    """The diarization consumer (hyperion/diarization/diar_ahc_plda.py:131-143): model projected
+    onto a PCA basis, every frame scored against every frame."""
+    from hyperion_amd.pdfs.plda import SPLDA
+
+    g = golden("splda_project")
+    p = SPLDA(mu=g["m_mu"], V=g["m_V"], W=g["m_W"]).project(g["T"], g["delta_mu"])
+    s = p.llr_1vs1(g["x"], g["x"])
+    err = np.abs(s - g["scores"]) / np.maximum(np.abs(g["scores"]), 1.0)
+    assert err.max() <= 1e-4, err.max()
+    assert np.max(np.abs(s - s.T)) <= 1e-4 * np.abs(s).max()

@@ -134,3 +134,20 @@ def test_medium(golden):
     close(s, g["scores"])
     # the calibrated synthetic model has scores on both sides of zero
     assert (s > 0).any() and (s < 0).any()
+
+
+def test_splda_project_matches_reference(golden):
+    """oracle and product SPLDA.project against the reference's projected model (host arithmetic)."""
+    from hyperion_amd.pdfs.plda import SPLDA
+
+    g = golden("splda_project")
+    mu, V, W = O.splda_project(g["m_mu"], g["m_V"], g["m_W"], g["T"], g["delta_mu"])
+    for got, want in ((mu, g["p_mu"]), (V, g["p_V"]), (W, g["p_W"])):
+        assert np.allclose(got, want, rtol=1e-10, atol=1e-12)
+    model = SPLDA(mu=g["m_mu"].copy(), V=g["m_V"], W=g["m_W"])
+    p = model.project(g["T"], g["delta_mu"])
+    assert np.allclose(p.mu, g["p_mu"], rtol=1e-10, atol=1e-12) and np.allclose(p.V, g["p_V"], rtol=1e-10)
+    assert np.allclose(p.W, g["p_W"], rtol=1e-9, atol=1e-12)
+    assert np.array_equal(model.mu, g["m_mu"])  # the model itself is not modified
+    s = O.llr_1vs1({"type": "splda", "mu": mu, "V": V, "W": W}, g["x"], g["x"])
+    assert np.allclose(s, g["scores"], rtol=1e-9, atol=1e-9)
