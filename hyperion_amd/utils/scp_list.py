@@ -130,19 +130,54 @@ class SCPList(object):
     def split(self, idx, num_parts, group_by_key=True):
         """Part `idx` of `num_parts` (scp_list.py:231-259)."""
         picker = split_list_group_by_key if group_by_key else split_list
-        key, loc = picker(self.key, idx, num_parts)
-        return SCPList(key, self.file_path[loc], None if self.offset is None else self.offset[loc],
-                       None if self.range_spec is None else self.range_spec[loc])
+        return self._subset(picker(self.key, idx, num_parts)[1])
 
-    def filter(self, filter_key, keep=True):
-        """Records with the given keys, in the order asked for (keep) or all the others."""
-        if not keep:
-            filter_key = np.setdiff1d(self.key, filter_key)
-        loc = np.array([self.get_index(k) for k in filter_key], dtype=np.int64)
+    def _subset(self, loc):
         return SCPList(self.key[loc], self.file_path[loc], None if self.offset is None else self.offset[loc],
                        None if self.range_spec is None else self.range_spec[loc])
 
+    @classmethod
+    def merge(cls, scp_lists):
+        """Concatenation of several lists (scp_list.py:261-289)."""
+        cat = lambda name: (None if getattr(scp_lists[0], name) is None  # noqa: E731
+                            else np.concatenate([getattr(s, name) for s in scp_lists]))
+        return cls(cat("key"), cat("file_path"), cat("offset"), cat("range_spec"))
+
+    def filter(self, filter_key, keep=True):
+        """All records whose key is in filter_key (or is not, keep=False), in list order; every
+        requested key must exist (scp_list.py:291-317)."""
+        return self._filter_by(self.key, filter_key, keep)
+
+    def filter_paths(self, filter_key, keep=True):
+        """As filter, by archive path (scp_list.py:319-346)."""
+        return self._filter_by(self.file_path, filter_key, keep)
+
+    def _filter_by(self, column, wanted, keep):
+        if not keep:
+            wanted = np.setdiff1d(column, wanted)
+        have = set(column.tolist())
+        assert all(w in have for w in wanted), "a requested entry is not in the list"
+        wanted = set(np.asarray(wanted).tolist())
+        return self._subset(np.fromiter((c in wanted for c in column.tolist()), dtype=bool, count=len(column)))
+
+    def filter_index(self, index, keep=True):
+        """Records at the given positions, in that order (scp_list.py:348-374)."""
+        if not keep:
+            index = np.setdiff1d(np.arange(len(self.key), dtype=np.int64), index)
+        return self._subset(np.asarray(index, dtype=np.int64))
+
+    def shuffle(self, seed=1024, rng=None):
+        """Random order in place; returns the permutation (scp_list.py:376-399)."""
+        rng = np.random.RandomState(seed=seed) if rng is None else rng
+        index = np.arange(len(self.key))
+        rng.shuffle(index)
+        self.key = self.key[index]
+        self._take(index)
+        return index
+
     def __eq__(self, other):
+        if len(self.key) == 0 and len(other.key) == 0:  # empty lists are equal whatever they carry
+            return True
         same = lambda a, b: (a is None) == (b is None) and (a is None or (a.shape == b.shape and np.all(a == b)))  # noqa: E731
         return (same(self.key, other.key) and same(self.file_path, other.file_path) and
                 same(self.offset, other.offset) and same(self.range_spec, other.range_spec))

@@ -44,9 +44,7 @@ class Utt2Info(object):
 
     def _positions(self):
         if self._index is None:
-            self._index = {}
-            for i, k in enumerate(self._key):
-                self._index.setdefault(k, i)
+            self._index = {k: i for i, k in enumerate(self._key)}
         return self._index
 
     def get_index(self, key):
