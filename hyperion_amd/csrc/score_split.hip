@@ -32,8 +32,9 @@
 // offset or offsets HS apart: with HS a multiple of 16 slots and an odd row pitch all 16 lanes of a
 // group land on different 16-byte bank slots.  At K = 150: 1008 bytes per row of triples, 848 of pairs.
 //
-// The kernel has the structure of score_rs_kernel: the split rows of 32 enrol vectors stay in
-// registers for the life of a wave (2 row tiles of 16), test rows stream through two LDS buffers by
+// The kernel has the structure of score_rs_kernel: the split rows of 32 enrol vectors (48 for pairs
+// up to 160 coordinates) stay in registers for the life of a wave (row tiles of 16), test rows stream
+// through two LDS buffers by
 // LDS-DMA in tiles of 32 rows (2 column tiles of 16), and a tile's scores leave through one buffer
 // descriptor after v_permlane16_swap has put the two column tiles of a row side by side (128-byte
 // segments).  The 16x16x32 shape is used because it sustains about 14 % more flop/s than 32x32x16
@@ -215,7 +216,9 @@ __device__ __forceinline__ void lds_dma_16_uniform(const void* sbase, unsigned v
 // Up to 160 coordinates (KS2 <= 5) a wave needs fewer than 256 registers and two workgroups share a
 // CU; wider rows keep up to 240 registers of stationary operand alone and run one wave per SIMD.
 // Pairs hold two thirds of that per row: two workgroups per CU up to KS2 = 7.
-template <int NP, int KS2>  // parts per value; k-steps of 32 coordinates
+// RT row tiles of 16 enrol rows per wave: three where the registers allow it (pairs up to KS2 = 5),
+// which spreads the per-tile barrier, LDS-DMA wait and operand reads over half as many more MFMAs.
+template <int NP, int KS2, int RT>  // parts per value; k-steps of 32 coordinates; row tiles per wave
 __global__ __launch_bounds__(256, (KS2 <= (NP == 3 ? 5 : 7) ? 2 : 1)) void score_split_kernel(const uint4* __restrict__ H1,
                                                              const uint4* __restrict__ H2,
                                                              float* __restrict__ S, int64_t n1,
@@ -237,12 +240,12 @@ __global__ __launch_bounds__(256, (KS2 <= (NP == 3 ? 5 : 7) ? 2 : 1)) void score
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
     const int my_slot = (kq & 1) * HS + NP * (kq >> 1);  // + 2 * NP * ks + s
-    const int64_t i0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const int64_t i0 = (int64_t)blockIdx.x * (64 * RT) + wave * (16 * RT);
 
     // stationary operand: a[rt][s][ks] = part s of H1[i0 + 16 rt + r16], coordinates 32 ks + 8 kq .. + 7
-    vec_t a[2][NP][KS2];
+    vec_t a[RT][NP][KS2];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
         int64_t row = i0 + 16 * rt + r16;
         if (row > n1 - 1) row = n1 - 1;
         const uint4* p = H1 + row * ROW_SLOTS + my_slot;
@@ -251,11 +254,11 @@ __global__ __launch_bounds__(256, (KS2 <= (NP == 3 ? 5 : 7) ? 2 : 1)) void score
 #pragma unroll
             for (int s = 0; s < NP; ++s) a[rt][s][ks] = __builtin_bit_cast(vec_t, p[2 * NP * ks + s]);
     }
-    // pairs: inverse scales of the eight enrol rows whose scores this lane holds after the MFMAs
+    // pairs: inverse scales of the 4 RT enrol rows whose scores this lane holds after the MFMAs
     // (row 16 rt + 4 (lane >> 4) + e of the wave's block)
-    float rs[2][4];
+    float rs[RT][4];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             rs[rt][e] = 1.f;
@@ -281,18 +284,19 @@ __global__ __launch_bounds__(256, (KS2 <= (NP == 3 ? 5 : 7) ? 2 : 1)) void score
     const int u = lane >> 5, c32 = lane & 31;
     const int vb = (int)(((unsigned)(8 * u) * (unsigned)ldo + (unsigned)c32) * 4u);
     const int row_bytes = (int)ldo * 4;
-    const unsigned span = 32u * (unsigned)ldo * 4u;
+    const unsigned span = (unsigned)(16 * RT) * (unsigned)ldo * 4u;
     float* const s_rows = S + i0 * ldo;
     // register p of a stored tile: rt = p >> 3, reg = (p >> 1) & 3, second of the swapped pair = p & 1
     auto prow = [](int p) { return 16 * (p >> 3) + ((p >> 1) & 3) + 4 * (p & 1); };
 
-    // A wave whose rows and whose chunk's columns are all in range issues exactly 16 stores per
-    // tile, so "all but the youngest 16 memory operations" is exactly "the next tile has landed".
-    const bool steady = (n1 - i0 >= 32) && ((tile0 + ntiles) * 32 <= n2);
+    // A wave whose rows and whose chunk's columns are all in range issues exactly 8 RT stores per
+    // tile, so "all but the youngest 8 RT memory operations" is exactly "the next tile has landed".
+    constexpr int NST = 8 * RT;
+    const bool steady = (n1 - i0 >= 16 * RT) && ((tile0 + ntiles) * 32 <= n2);
 
     auto run = [&](auto steady_tag) {
         constexpr bool ST = decltype(steady_tag)::value;
-        constexpr int NSIDE = ST ? NPW + 16 : 0;  // DMA pieces, then stores, between the MFMA groups
+        constexpr int NSIDE = ST ? NPW + NST : 0;  // DMA pieces, then stores, between the MFMA groups
         constexpr int NSLOT = 2 * NP * KS2;
 
         auto stage_piece = [&](int it, int buf, int p) {
@@ -310,9 +314,9 @@ __global__ __launch_bounds__(256, (KS2 <= (NP == 3 ? 5 : 7) ? 2 : 1)) void score
             }
         };
 
-        float prev[16];
+        float prev[NST];
 #pragma unroll
-        for (int p = 0; p < 16; ++p) prev[p] = 0.f;
+        for (int p = 0; p < NST; ++p) prev[p] = 0.f;
 
 #pragma unroll
         for (int p = 0; p < NPW; ++p) stage_piece(0, 0, p);
@@ -320,7 +324,8 @@ __global__ __launch_bounds__(256, (KS2 <= (NP == 3 ? 5 : 7) ? 2 : 1)) void score
         for (int it = 0; it < ntiles; ++it) {
             const int buf = it & 1;
             if (ST && it > 0) {
-                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                if constexpr (RT == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -337,9 +342,9 @@ __global__ __launch_bounds__(256, (KS2 <= (NP == 3 ? 5 : 7) ? 2 : 1)) void score
             __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 s_rows + (tile0 + it - 1) * 32, 0, it > 0 ? span : 0u, 0x00020000);
 
-            f32x4 hi[2][2], mid[2][2], lo[2][2];  // pairs use hi and lo only
+            f32x4 hi[RT][2], mid[RT][2], lo[RT][2];  // pairs use hi and lo only
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
+            for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(256, (KS2 <= (NP == 3 ? 5 : 7) ? 2 : 1)) void score
                     for (int g = 0; g < NP; ++g) {
                         nb[g] = __builtin_bit_cast(vec_t, bt[16 * nct * ROW_SLOTS + 2 * NP * nks + g]);
 #pragma unroll
-                        for (int rt = 0; rt < 2; ++rt) {
+                        for (int rt = 0; rt < RT; ++rt) {
                             if constexpr (NP == 3) {
                                 if (g == 0) {
                                     mid[rt][ct] = Fmt::mfma(a[rt][1][ks], b[0], mid[rt][ct]);
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(256, (KS2 <= (NP == 3 ? 5 : 7) ? 2 : 1)) void score
             // sum of the classes (and un-scaling), then the two column tiles of a row side by side:
             // X' = [X.q0 Y.q0 X.q2 Y.q2], Y' = [X.q1 Y.q1 X.q3 Y.q3]  (q = 16-lane group = 4 rows)
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 f32x4 x, y;
                 if constexpr (NP == 3) {
                     x = hi[rt][0] + (mid[rt][0] + lo[rt][0]);
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(256, (KS2 <= (NP == 3 ? 5 : 7) ? 2 : 1)) void score
                 const int64_t rows_left = n1 - i0;  // wave-uniform
                 if (col < n2) {
 #pragma unroll
-                    for (int p = 0; p < 16; ++p) {
+                    for (int p = 0; p < NST; ++p) {
                         const int rr = prow(p) + 8 * u;
                         if (rr < rows_left) __builtin_nontemporal_store(prev[p], s_rows + rr * ldo + col);
                     }
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(256, (KS2 <= (NP == 3 ? 5 : 7) ? 2 : 1)) void score
             __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 s_rows + (tile0 + ntiles - 1) * 32, 0, span, 0x00020000);
 #pragma unroll
-            for (int p = 0; p < 16; ++p)
+            for (int p = 0; p < NST; ++p)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(prev[p]), rsrc, vb, prow(p) * row_bytes, 2);
         }
     };
@@ -465,13 +470,14 @@ static int launch_split(const uint4* H1, int64_t n1, const uint4* H2, int64_t n2
     constexpr int PIECES = (32 * split_row_slots(2 * KS2, NP) + 63) / 64;
     constexpr int LDS_BYTES = 2 * PIECES * 64 * 16;
     static_assert(LDS_BYTES <= 160 * 1024, "tile buffers exceed the LDS");
+    constexpr int RT = (NP == 2 && KS2 <= 5) ? 3 : 2;
     LaunchGeom g;
-    int rc = launch_geometry(n1, n2, 128, &g);
+    int rc = launch_geometry(n1, n2, 64 * RT, &g);
     if (rc != HYPMI_OK) return rc;
     if (LDS_BYTES > 48 * 1024)
-        HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_split_kernel<NP, KS2>),
+        HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_split_kernel<NP, KS2, RT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    hipLaunchKernelGGL((score_split_kernel<NP, KS2>), dim3((unsigned)g.gx, (unsigned)g.gy), dim3(256), LDS_BYTES,
+    hipLaunchKernelGGL((score_split_kernel<NP, KS2, RT>), dim3((unsigned)g.gx, (unsigned)g.gy), dim3(256), LDS_BYTES,
                        stream, H1, H2, S, n1, n2, lds, g.tiles_per_chunk);
     HYPMI_HIP(hipGetLastError());
     return HYPMI_OK;
