@@ -254,20 +254,17 @@ __global__ __launch_bounds__(256, (KS2 <= (NP == 3 ? 5 : 7) ? 2 : 1)) void score
 #pragma unroll
             for (int s = 0; s < NP; ++s) a[rt][s][ks] = __builtin_bit_cast(vec_t, p[2 * NP * ks + s]);
     }
-    // pairs: inverse scales of the 4 RT enrol rows whose scores this lane holds after the MFMAs
-    // (row 16 rt + 4 (lane >> 4) + e of the wave's block)
-    float rs[RT][4];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            rs[rt][e] = 1.f;
-            if constexpr (NP == 2) {
-                int64_t row = i0 + 16 * rt + 4 * kq + e;
-                if (row > n1 - 1) row = n1 - 1;
-                rs[rt][e] = __uint_as_float(H1[row * ROW_SLOTS + ROW_SLOTS - 1].x);
-            }
+    // pairs: inverse scales of the wave's 16 RT enrol rows, parked in LDS behind the tile buffers (a
+    // lane needs those of rows 16 rt + 4 (lane >> 4) + e only when a tile is summed; keeping them in
+    // registers across the MFMA loop costs 4 RT registers the three-tile variant does not have)
+    float* const row_scale = reinterpret_cast<float*>(tile + 2 * BUF_SLOTS) + wave * (16 * RT);
+    if constexpr (NP == 2) {
+        if (lane < 16 * RT) {
+            int64_t row = i0 + lane;
+            if (row > n1 - 1) row = n1 - 1;
+            row_scale[lane] = __uint_as_float(H1[row * ROW_SLOTS + ROW_SLOTS - 1].x);
         }
+    }
 
     const int64_t tile0 = (int64_t)blockIdx.y * tiles_per_chunk;
     const int64_t ntiles_all = (n2 + 31) / 32;
@@ -422,13 +419,9 @@ __global__ __launch_bounds__(256, (KS2 <= (NP == 3 ? 5 : 7) ? 2 : 1)) void score
                     x = hi[rt][0] + (mid[rt][0] + lo[rt][0]);
                     y = hi[rt][1] + (mid[rt][1] + lo[rt][1]);
                 } else {
-                    x = hi[rt][0] + lo[rt][0];
-                    y = hi[rt][1] + lo[rt][1];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        x[e] = (x[e] * rs[rt][e]) * cs[0];
-                        y[e] = (y[e] * rs[rt][e]) * cs[1];
-                    }
+                    const f32x4 rs = *reinterpret_cast<const f32x4*>(row_scale + 16 * rt + 4 * kq);
+                    x = ((hi[rt][0] + lo[rt][0]) * rs) * cs[0];
+                    y = ((hi[rt][1] + lo[rt][1]) * rs) * cs[1];
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -468,7 +461,7 @@ template <int NP, int KS2>
 static int launch_split(const uint4* H1, int64_t n1, const uint4* H2, int64_t n2, float* S, int64_t lds,
                         hipStream_t stream) {
     constexpr int PIECES = (32 * split_row_slots(2 * KS2, NP) + 63) / 64;
-    constexpr int LDS_BYTES = 2 * PIECES * 64 * 16;
+    constexpr int LDS_BYTES = 2 * PIECES * 64 * 16 + 1024;  // two tile buffers + the enrol rows' scales
     static_assert(LDS_BYTES <= 160 * 1024, "tile buffers exceed the LDS");
     constexpr int RT = (NP == 2 && KS2 <= 5) ? 3 : 2;
     LaunchGeom g;
