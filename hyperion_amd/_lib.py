@@ -117,6 +117,8 @@ SIGNATURES = {
                                          ctypes.c_float, c_void_p, c_void_p, c_void_p]),
     "hypmi_norm_apply": (ctypes.c_int, [c_void_p, i64, i64, i64, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, i64, c_void_p]),
+    "hypmi_gram_f64": (ctypes.c_int, [c_void_p, i64, i64, ctypes.c_int, c_void_p, c_void_p, i64, c_void_p,
+                                      c_void_p]),
     "hypmi_ark_probe": (ctypes.c_int, [ctypes.c_char_p, i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hypmi_ark_read_vectors": (ctypes.c_int, [c_void_p, i32, c_void_p, c_void_p, c_void_p, i64, i32, i32,
                                               c_void_p, i64, i32]),

@@ -1,0 +1,155 @@
+// Second-order statistics for the training side of the back-end (whitening, LDA, PLDA statistics):
+//   C = sum_s w_s x_s x_s^T   (d x d, float64),   F = sum_s w_s x_s
+// over n float64 rows.  Replaces np.dot(x.T, x) / np.dot(wx.T, x) (hyperion/pdfs/core/normal.py:102-113,
+// hyperion/pdfs/plda/plda_base.py:268-272) and, with w = 1 / N_class and the class means, the per-class
+// scatter loop of hyperion/transforms/sb_sw.py:36-43.
+//
+// Gram kernel: f64 matrix cores (v_mfma_f64_16x16x4_f64, the sample index is the contraction).  A
+// wave owns a 64 x 64 block of C (4 x 4 tiles) and a range of samples; its operands come straight
+// from global memory in operand layout (lane l reads feature f0 + (l & 15) of sample s0 + (l >> 4):
+// four 128-byte row segments per load), the next step's eight loads are in flight while the sixteen
+// MFMAs of the current one run, and the block is added to C with float64 atomics at the end.  Only
+// blocks on or above the diagonal are computed; off-diagonal blocks are added to both halves.
+// A wave that ends early returns before anything collective: the kernel has no barrier.
+#include "common.h"
+
+namespace {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GB = 64;  // features per block side
+
+__global__ __launch_bounds__(256) void gram_f64_kernel(const double* __restrict__ X, int64_t ldx, int64_t n,
+                                                       int d, const double* __restrict__ w,
+                                                       int64_t samples_per_wave, double* __restrict__ C,
+                                                       int64_t ldc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // blockIdx.x runs over the block pairs (bi <= bj) row by row
+    const int nblk = (d + GB - 1) / GB;
+    int bi = 0, bj = (int)blockIdx.x;
+    while (bj >= nblk - bi) {
+        bj -= nblk - bi;
+        ++bi;
+    }
+    bj += bi;
+    const int f0 = bi * GB, g0 = bj * GB;
+    const int64_t s_begin = ((int64_t)blockIdx.y * 4 + wave) * samples_per_wave;
+    int64_t s_end = s_begin + samples_per_wave;
+    if (s_end > n) s_end = n;
+    if (s_begin >= s_end) return;
+
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0;
+
+    // Loads are unconditional (clamped to an existing feature and sample) and masked afterwards, so
+    // that the eight loads of a step are issued back to back and none waits for another.
+    bool fa[4], fb[4];  // feature columns of this lane that exist
+    int ca[4], cb[4];   // ... clamped into the row
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        fa[t] = f0 + 16 * t + l15 < d;
+        fb[t] = g0 + 16 * t + l15 < d;
+        ca[t] = fa[t] ? f0 + 16 * t + l15 : d - 1;
+        cb[t] = fb[t] ? g0 + 16 * t + l15 : d - 1;
+    }
+    auto fetch = [&](int64_t s0, double (&a)[4], double (&b)[4]) {
+        const int64_t s = s0 + l4;
+        const bool live = s < s_end;
+        const int64_t sc = live ? s : s_end - 1;
+        const double* row = X + sc * ldx;
+        double va[4], vb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            va[t] = row[ca[t]];
+            vb[t] = row[cb[t]];
+        }
+        const double ws = w ? w[sc] : 1.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a[t] = (live && fa[t]) ? va[t] : 0.0;
+            b[t] = (live && fb[t]) ? vb[t] * ws : 0.0;
+        }
+    };
+
+    double a[4], b[4], na[4], nb[4];
+    fetch(s_begin, a, b);
+    for (int64_t s0 = s_begin; s0 < s_end; s0 += 4) {
+        fetch(s0 + 4, na, nb);  // past the range: zeros
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a[t] = na[t];
+            b[t] = nb[t];
+        }
+    }
+    // D layout: column = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int f = f0 + 16 * i + l4 + 4 * e, g = g0 + 16 * j + l15;
+                if (f < d && g < d) {
+                    atomicAdd(&C[(int64_t)f * ldc + g], acc[i][j][e]);
+                    if (bi != bj) atomicAdd(&C[(int64_t)g * ldc + f], acc[i][j][e]);
+                }
+            }
+}
+
+// F[c] += sum_s w_s X[s, c]: one thread per column and row slab, coalesced across columns.
+__global__ __launch_bounds__(256) void colsum_f64_kernel(const double* __restrict__ X, int64_t ldx, int64_t n,
+                                                         int d, const double* __restrict__ w,
+                                                         int64_t rows_per_block, double* __restrict__ F) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    double s = 0.0;
+    for (int64_t r = r0; r < r1; ++r) s += X[r * ldx + c] * (w ? w[r] : 1.0);
+    if (r1 > r0) atomicAdd(&F[c], s);
+}
+
+}  // namespace
+
+extern "C" int hypmi_gram_f64(const double* X, int64_t n, int64_t ldx, int d, const double* w, double* C,
+                              int64_t ldc, double* F, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HYPMI_REQUIRE(n >= 0 && d > 0 && ldx >= d && ldc >= d, "gram_f64: bad shape");
+    HYPMI_REQUIRE(C, "gram_f64: null result");
+    HYPMI_HIP(hipMemsetAsync(C, 0, (size_t)d * (size_t)ldc * sizeof(double), stream));
+    if (F) HYPMI_HIP(hipMemsetAsync(F, 0, (size_t)d * sizeof(double), stream));
+    if (n == 0) return HYPMI_OK;
+    HYPMI_REQUIRE(X, "gram_f64: null pointer");
+    const int nb = (d + GB - 1) / GB;
+    const int npairs = nb * (nb + 1) / 2;  // blocks on and above the diagonal
+    // about 2048 workgroups in all; a wave walks at least 64 samples
+    int64_t chunks = (2048 + npairs - 1) / npairs;
+    const int64_t max_chunks = (n + 4 * 64 - 1) / (4 * 64);
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks > 65535) chunks = 65535;
+    if (chunks < 1) chunks = 1;
+    int64_t samples_per_wave = (n + chunks * 4 - 1) / (chunks * 4);
+    samples_per_wave = (samples_per_wave + 3) / 4 * 4;
+    hipLaunchKernelGGL(gram_f64_kernel, dim3((unsigned)npairs, (unsigned)chunks), dim3(256), 0, stream, X, ldx, n,
+                       d, w, samples_per_wave, C, ldc);
+    if (F) {
+        int64_t slabs = (n + 4095) / 4096;
+        if (slabs > 65535) slabs = 65535;
+        const int64_t rows_per_block = (n + slabs - 1) / slabs;
+        hipLaunchKernelGGL(colsum_f64_kernel, dim3((unsigned)((d + 255) / 256), (unsigned)slabs), dim3(256), 0,
+                           stream, X, ldx, n, d, w, rows_per_block, F);
+    }
+    HYPMI_HIP(hipGetLastError());
+    return HYPMI_OK;
+}

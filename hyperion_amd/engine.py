@@ -77,6 +77,26 @@ def upload64(x):
     return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).cuda()
 
 
+def gram64(x, w=None):
+    """(sum_s w_s x_s x_s^T, sum_s w_s x_s) as device float64 tensors [d, d] and [d]; x numpy or
+    device [n, d], w optional row weights [n]."""
+    torch = require_gpu()
+    X = upload64(x)
+    n, d = X.shape
+    W = None
+    if w is not None:
+        W = (w if isinstance(w, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(w, dtype=np.float64)))
+        W = W.to(device="cuda", dtype=torch.float64).contiguous()
+        assert W.shape == (n,)
+    C = torch.empty((d, d), dtype=torch.float64, device="cuda")
+    F = torch.empty((d,), dtype=torch.float64, device="cuda")
+    _lib.check(_lib.load().hypmi_gram_f64(_ptr(X), n, X.stride(0) if n > 1 else d, d,
+                                          ctypes.c_void_p(0) if W is None else _ptr(W), _ptr(C), d, _ptr(F),
+                                          stream_ptr()))
+    # the two halves are summed by different workgroups in different orders: make them one matrix
+    return 0.5 * (C + C.T), F
+
+
 # fp32 error model of one score: |err| <= ERR_COEFF * (|g1| |g2| + |q1| + |q2|), 8 units of 2^-24
 ERR_COEFF = 8.0 * 2.0 ** -24
 

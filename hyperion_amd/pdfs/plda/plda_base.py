@@ -132,19 +132,27 @@ class PLDABase(HypModel):
     # ---- sufficient statistics ----------------------------------------------------------------
     @staticmethod
     def compute_stats_hard(x, class_ids, sample_weight=None, scale_factor=None):
-        """(N, F, S) per class for classes 0..max(id) (plda_base.py:249-274).  N and F are
-        computed on the GPU; the second-order statistic S is returned as None because no scoring
-        path reads it (training is outside this package)."""
+        """(N, F, S) per class for classes 0..max(id) (plda_base.py:249-274): counts, per-class
+        sums (fp32 segmented sums on the GPU) and the global second-order statistic S = x^T x
+        (float64 matrix cores).  With sample_weight w: N = sum w, F = sum w x, S = (w x)^T x."""
+        torch = engine.require_gpu()
+        xd = engine.upload(x)
         if sample_weight is not None:
-            raise NotImplementedError("sample weights belong to training, which is not part of "
-                                      "the scoring path")
-        F_dev, counts = pool_rows(engine.upload(x), class_ids, mean=False)
-        N = counts.astype(float_cpu())
+            w = torch.from_numpy(np.ascontiguousarray(sample_weight, dtype=np.float32)).to(xd.device)
+            F_dev, _ = pool_rows(xd * w[:, None], class_ids, mean=False)
+            ids = np.asarray(class_ids).astype(np.int64).reshape(-1)
+            N = np.bincount(ids, weights=np.asarray(sample_weight, dtype=np.float64),
+                            minlength=F_dev.shape[0]).astype(float_cpu())
+        else:
+            F_dev, counts = pool_rows(xd, class_ids, mean=False)
+            N = counts.astype(float_cpu())
         F = engine.to_host(F_dev, float_cpu())
+        S = engine.gram64(x, sample_weight)[0].cpu().numpy().astype(float_cpu())
         if scale_factor is not None:
             N = N * scale_factor
             F = F * scale_factor
-        return N, F, None
+            S = S * scale_factor
+        return N, F, S
 
     # ---- N vs M -----------------------------------------------------------------------------
     def _pooled_mean(self, x, ids):

@@ -3,6 +3,7 @@ from .cent_whiten import CentWhiten
 from .lnorm import LNorm
 from .lda import LDA
 from .pca import PCA
+from .sb_sw import SbSw
 from .transform_list import TransformList
 
-__all__ = ["CentWhiten", "LNorm", "LDA", "PCA", "TransformList"]
+__all__ = ["CentWhiten", "LNorm", "LDA", "PCA", "SbSw", "TransformList"]

@@ -263,6 +263,17 @@ int hypmi_norm_apply(const float* S, int64_t lds, int64_t ne, int64_t nt, const 
                      const float* iz, const float* mt, const float* it, float* out, int64_t ldo,
                      void* stream);
 
+/* ---- training statistics ---------------------------------------------------------------------- */
+
+/* C = sum_s w_s x_s x_s^T (d x d, both halves) and optionally F = sum_s w_s x_s over n float64 rows
+ * X [n x ldx]; w (n, optional) are row weights.  f64 matrix cores.  Replaces np.dot(x.T, x) /
+ * np.dot(wx.T, x) and np.sum(x, axis=0) of hyperion/pdfs/core/normal.py:102-113 and
+ * hyperion/pdfs/plda/plda_base.py:268-272; with w = 1 / N_class it is the sum over classes of the
+ * per-class scatter loop of hyperion/transforms/sb_sw.py:36-43 before the class means are taken
+ * out.  C and F are overwritten. */
+int hypmi_gram_f64(const double* X, int64_t n, int64_t ldx, int d, const double* w, double* C,
+                   int64_t ldc, double* F, void* stream);
+
 /* ---- x-vector loading (HOST functions: host pointers, no device, no stream) ------------------- */
 
 /* Shape of the record at byte `offset` of a Kaldi binary archive (the position an scp line names,

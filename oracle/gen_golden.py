@@ -300,8 +300,53 @@ def gen_project():
     print("project ok")
 
 
+def gen_training_stats():
+    """Whitening / LDA fits and PLDA sufficient statistics of the reference on labelled vectors
+    (hyperion/transforms/cent_whiten.py:35-62, sb_sw.py:25-50, lda.py:36-68,
+    hyperion/pdfs/plda/plda_base.py:249-274)."""
+    from hyperion.transforms.sb_sw import SbSw
+
+    rng = np.random.RandomState(31)
+    n, d, ncls = 400, 10, 23
+    y = rng.randint(0, ncls, n)
+    y[:ncls] = np.arange(ncls)
+    centres = 2.0 * rng.randn(ncls, d)
+    x = centres[y] + rng.randn(n, d) * np.exp(rng.uniform(-1, 1, d)) + 3.0
+    w = rng.uniform(0.5, 2.0, n)
+    out = dict(x=x, y=y, w=w)
+    cw = R.CentWhiten()
+    cw.fit(x)
+    out["cw_mu"], out["cw_T"] = cw.mu, cw.T
+    mu, T = O.cent_whiten_fit(x)
+    close(mu, cw.mu), close(T, cw.T, 1e-8)
+    cww = R.CentWhiten()
+    cww.fit(x, sample_weight=w)
+    out["cww_mu"], out["cww_T"] = cww.mu, cww.T
+    mu, T = O.cent_whiten_fit(x, w)
+    close(mu, cww.mu), close(T, cww.T, 1e-8)
+    few = R.CentWhiten()
+    few.fit(x[:6])
+    out["few_mu"], out["few_T"] = few.mu, few.T
+    sb = SbSw()
+    sb.fit(x, y)
+    out["sb_mu"], out["sb_Sb"], out["sb_Sw"] = sb.mu, sb.Sb, sb.Sw
+    mu, Sb, Sw = O.sb_sw(x, y)
+    close(mu, sb.mu), close(Sb, sb.Sb), close(Sw, sb.Sw)
+    lda = R.LDA(lda_dim=6)
+    lda.fit(x, y)
+    out["lda_mu"], out["lda_T"] = lda.mu, lda.T
+    mu, T = O.lda_fit(x, y, 6)
+    close(mu, lda.mu), close(T, lda.T, 1e-8)
+    for tag, kw in (("", {}), ("w_", dict(sample_weight=w, scale_factor=0.5))):
+        N, F, S = R.SPLDA.compute_stats_hard(x, y, **kw)
+        out["st_" + tag + "N"], out["st_" + tag + "F"], out["st_" + tag + "S"] = N, F, S
+    np.savez_compressed(os.path.join(OUT, "training_stats.npz"), **out)
+    print("training stats ok")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    gen_training_stats()
     gen_project()
     gen_selfcheck()
     gen_1vs1()

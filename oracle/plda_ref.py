@@ -388,6 +388,49 @@ def s_norm(scores, scores_coh_test, scores_enr_coh, mask_coh_test=None, mask_enr
     return (z + t) / np.sqrt(2)
 
 
+# ----------------------------------------------------------------------------- training statistics
+def sb_sw(x, class_ids):
+    """SbSw.fit + normalize (hyperion/transforms/sb_sw.py:25-50): (mu, Sb, Sw)."""
+    dim = x.shape[1]
+    Sb, Sw, mu = np.zeros((dim, dim)), np.zeros((dim, dim)), np.zeros(dim)
+    u_ids = np.unique(class_ids)
+    for i in u_ids:
+        xi = x[class_ids == i]
+        mi = np.mean(xi, axis=0)
+        mu += mi
+        Sb += np.outer(mi, mi)
+        Sw += (xi - mi).T @ (xi - mi) / len(xi)
+    mu /= len(u_ids)
+    return mu, Sb / len(u_ids) - np.outer(mu, mu), Sw / len(u_ids)
+
+
+def _largest_first_positive_top(V):
+    V = np.fliplr(V)
+    V[:, V[0, :] < 0] *= -1
+    return V
+
+
+def cent_whiten_fit(x, sample_weight=None):
+    """CentWhiten.fit from data with more vectors than dimensions (cent_whiten.py:35-62, moments
+    as hyperion/pdfs/core/normal.py:102-143): (mu, T)."""
+    if sample_weight is None:
+        N, F, S = x.shape[0], x.sum(axis=0), x.T @ x
+    else:
+        wx = sample_weight[:, None] * x
+        N, F, S = sample_weight.sum(), wx.sum(axis=0), wx.T @ x
+    mu = F / N
+    d, V = sla.eigh(S / N - np.outer(mu, mu))
+    return mu, _largest_first_positive_top(V * np.sqrt(1 / d))
+
+
+def lda_fit(x, y, lda_dim=None):
+    """LDA.fit (hyperion/transforms/lda.py:36-68): (mu, T)."""
+    mu, Sb, Sw = sb_sw(x, y)
+    _, V = sla.eigh(Sb, Sw)
+    V = _largest_first_positive_top(V)
+    return mu, V if lda_dim is None else V[:, :lda_dim]
+
+
 # ----------------------------------------------------------------------------- metrics (gate)
 def pavx(y):
     """Pool-adjacent-violators (hyperion/metrics/utils.py:30-94): returns (ghat, width, height)."""

@@ -151,3 +151,17 @@ def test_splda_project_matches_reference(golden):
     assert np.array_equal(model.mu, g["m_mu"])  # the model itself is not modified
     s = O.llr_1vs1({"type": "splda", "mu": mu, "V": V, "W": W}, g["x"], g["x"])
     assert np.allclose(s, g["scores"], rtol=1e-9, atol=1e-9)
+
+
+def test_training_statistics_restatement(golden):
+    """Whitening / LDA fits of the oracle against the reference's (fixtures made by
+    oracle/gen_golden.py gen_training_stats)."""
+    g = golden("training_stats")
+    mu, T = O.cent_whiten_fit(g["x"])
+    assert np.allclose(mu, g["cw_mu"], rtol=1e-12) and np.allclose(T, g["cw_T"], rtol=1e-8, atol=1e-10)
+    mu, T = O.cent_whiten_fit(g["x"], g["w"])
+    assert np.allclose(mu, g["cww_mu"], rtol=1e-12) and np.allclose(T, g["cww_T"], rtol=1e-8, atol=1e-10)
+    mu, Sb, Sw = O.sb_sw(g["x"], g["y"])
+    assert np.allclose(mu, g["sb_mu"]) and np.allclose(Sb, g["sb_Sb"]) and np.allclose(Sw, g["sb_Sw"])
+    mu, T = O.lda_fit(g["x"], g["y"], 6)
+    assert np.allclose(mu, g["lda_mu"]) and np.allclose(T, g["lda_T"], rtol=1e-8, atol=1e-10)
