@@ -90,7 +90,7 @@ void convert_row(const unsigned char* src, int elem_bytes, int dim, int out_f64,
 }
 
 void read_range(const ReadJob& job, int64_t i0, int64_t i1, Failure* fail) {
-    std::vector<int> fds;  // one descriptor per archive, opened on first use by this thread
+    int fd = -1, fd_archive = -1;  // one open archive at a time (callers pass records grouped by archive)
     std::vector<unsigned char> buf;
     const int64_t rec_max = ARK_MAX_HEADER + (int64_t)job.dim * 8;
     auto out_row = [&](int64_t i) {
@@ -105,10 +105,11 @@ void read_range(const ReadJob& job, int64_t i0, int64_t i1, Failure* fail) {
         while (j < i1 && job.archive_of[j] == a && job.offsets[j] > job.offsets[j - 1] &&
                job.offsets[j] + rec_max - job.offsets[i] <= ARK_SPAN_BYTES)
             ++j;
-        if ((size_t)a >= fds.size()) fds.resize((size_t)a + 1, -1);
-        if (fds[a] < 0) {
-            fds[a] = open(job.archives[a], O_RDONLY | O_CLOEXEC);
-            if (fds[a] < 0) {
+        if (fd_archive != a) {
+            if (fd >= 0) close(fd);
+            fd = open(job.archives[a], O_RDONLY | O_CLOEXEC);
+            fd_archive = a;
+            if (fd < 0) {
                 fail->report(i, std::string("cannot open ") + job.archives[a] + ": " + strerror(errno));
                 break;
             }
@@ -118,7 +119,7 @@ void read_range(const ReadJob& job, int64_t i0, int64_t i1, Failure* fail) {
         buf.resize((size_t)want);
         int64_t got = 0;
         while (got < want) {
-            const ssize_t r = pread(fds[a], buf.data() + got, (size_t)(want - got), (off_t)(base + got));
+            const ssize_t r = pread(fd, buf.data() + got, (size_t)(want - got), (off_t)(base + got));
             if (r < 0 && errno == EINTR) continue;
             if (r <= 0) break;  // error or end of file: whatever arrived is checked record by record
             got += r;
@@ -140,8 +141,7 @@ void read_range(const ReadJob& job, int64_t i0, int64_t i1, Failure* fail) {
         }
         i = j;
     }
-    for (int fd : fds)
-        if (fd >= 0) close(fd);
+    if (fd >= 0) close(fd);
 }
 
 }  // namespace

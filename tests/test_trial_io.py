@@ -179,3 +179,24 @@ def test_class_keys_of_a_block_key():
     assert np.array_equal(km[:, None] == ks[None, :], tar) and km.min() >= 0 and ks.min() >= 0
     key.non[0, 0] = False  # a hole in the trial matrix: no class description
     assert key.class_keys() is None
+
+
+def test_keys_spread_over_several_archives(tmp_path):
+    """One script over three archives, keys asked for in an order that hops between them."""
+    from hyperion_amd.io import ArkDataWriter, RandomAccessArkDataReader
+
+    rng = np.random.RandomState(8)
+    x = rng.randn(90, 12).astype(np.float32)
+    keys = ["k%03d" % i for i in range(90)]
+    lines = []
+    for a in range(3):
+        ark, scp = str(tmp_path / ("p%d.ark" % a)), str(tmp_path / ("p%d.scp" % a))
+        with ArkDataWriter(ark, scp) as w:
+            w.write(keys[a::3], x[a::3])
+        lines += open(scp).read().splitlines()
+    rng.shuffle(lines)
+    (tmp_path / "all.scp").write_text("\n".join(lines) + "\n")
+    r = RandomAccessArkDataReader(str(tmp_path / "all.scp"), num_threads=4)
+    order = rng.permutation(90)
+    assert np.array_equal(r.read([keys[i] for i in order], squeeze=True), x[order])
+    assert np.array_equal(r.read(keys, squeeze=True), x)
