@@ -365,6 +365,17 @@ def main():
         "unit": "GB/s", "frac": pro_bytes / (pro_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "algorithmic_bytes": pro_bytes,
         "note": "matrix-core bound in practice (2 x 512 x 350 flop per vector on the fp32 MFMA)"}
+    # the same launch against the HBM roof: the score matrix written once plus both operands read once
+    # (with 16-bit operands the matrix pipes need less time than the 4 bytes per score need HBM)
+    from hyperion_amd import _lib
+
+    row_bytes = 4.0 * plan.kp
+    if use_split:
+        row_bytes = float(getattr(_lib.load(), engine.SPLIT_FORMATS[fmt][0])(plan.kp))
+    hbm_bytes = 4.0 * n1 * n2 + (n1 + n2) * row_bytes
+    out["roofline"]["hbm"] = {"bound": "hbm", "achieved": hbm_bytes / (score_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": hbm_bytes / (score_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "algorithmic_bytes_per_launch": hbm_bytes}
     if use_split:
         out["roofline"]["executed"] = {
             "pipe": "%s MFMA (%d partial products per fp32 product, K + 2 packed columns)"
