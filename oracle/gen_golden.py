@@ -337,6 +337,12 @@ def gen_training_stats():
     out["lda_mu"], out["lda_T"] = lda.mu, lda.T
     mu, T = O.lda_fit(x, y, 6)
     close(mu, lda.mu), close(T, lda.T, 1e-8)
+    for tag, kw in (("pca3_", dict(pca_dim=3)), ("pcar_", dict(pca_var_r=0.8, whiten=True))):
+        pca = R.PCA(**kw)
+        pca.fit(x)
+        out[tag + "mu"], out[tag + "T"] = pca.mu, pca.T
+        mu, T = O.pca_fit(x, **kw)
+        close(mu, pca.mu), close(T, pca.T, 1e-8)
     for tag, kw in (("", {}), ("w_", dict(sample_weight=w, scale_factor=0.5))):
         N, F, S = R.SPLDA.compute_stats_hard(x, y, **kw)
         out["st_" + tag + "N"], out["st_" + tag + "F"], out["st_" + tag + "S"] = N, F, S

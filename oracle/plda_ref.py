@@ -423,6 +423,19 @@ def cent_whiten_fit(x, sample_weight=None):
     return mu, _largest_first_positive_top(V * np.sqrt(1 / d))
 
 
+def pca_fit(x, pca_dim=None, pca_var_r=None, pca_min_dim=2, whiten=False):
+    """PCA.fit (hyperion/transforms/pca.py:61-106): (mu, T)."""
+    mu = np.mean(x, axis=0)
+    d, V = sla.eigh((x - mu).T @ (x - mu) / x.shape[0])
+    d, V = np.flip(d), _largest_first_positive_top(V)
+    if pca_var_r is not None:
+        share = np.cumsum(d) / np.sum(d)
+        pca_dim = max(np.where(share > pca_var_r)[0][0], pca_min_dim)
+    if whiten:
+        V = V / np.sqrt(d)
+    return mu, V if pca_dim is None else V[:, :pca_dim]
+
+
 def lda_fit(x, y, lda_dim=None):
     """LDA.fit (hyperion/transforms/lda.py:36-68): (mu, T)."""
     mu, Sb, Sw = sb_sw(x, y)

@@ -68,6 +68,13 @@ def test_fits_match_reference(golden):
     lda = LDA(lda_dim=6)
     lda.fit(x, y)
     assert np.allclose(lda.mu, g["lda_mu"], rtol=1e-10) and np.allclose(lda.T, g["lda_T"], rtol=1e-6, atol=1e-8)
+    from hyperion_amd.transforms import PCA
+
+    for tag, kw in (("pca3_", dict(pca_dim=3)), ("pcar_", dict(pca_var_r=0.8, whiten=True))):
+        pca = PCA(**kw)
+        pca.fit(x)
+        assert pca.T.shape == g[tag + "T"].shape
+        assert np.allclose(pca.mu, g[tag + "mu"], rtol=1e-12) and np.allclose(pca.T, g[tag + "T"], rtol=1e-7, atol=1e-9)
     # fitted transforms run through the device prologue like loaded ones
     z = lda.predict(cw.predict(x))
     assert z.shape == (len(x), 6) and np.all(np.isfinite(z))

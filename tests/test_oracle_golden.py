@@ -165,3 +165,6 @@ def test_training_statistics_restatement(golden):
     assert np.allclose(mu, g["sb_mu"]) and np.allclose(Sb, g["sb_Sb"]) and np.allclose(Sw, g["sb_Sw"])
     mu, T = O.lda_fit(g["x"], g["y"], 6)
     assert np.allclose(mu, g["lda_mu"]) and np.allclose(T, g["lda_T"], rtol=1e-8, atol=1e-10)
+    for tag, kw in (("pca3_", dict(pca_dim=3)), ("pcar_", dict(pca_var_r=0.8, whiten=True))):
+        mu, T = O.pca_fit(g["x"], **kw)
+        assert T.shape == g[tag + "T"].shape and np.allclose(T, g[tag + "T"], rtol=1e-8, atol=1e-10)
