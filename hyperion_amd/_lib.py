@@ -122,6 +122,9 @@ SIGNATURES = {
     "hypmi_ark_probe": (ctypes.c_int, [ctypes.c_char_p, i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hypmi_ark_read_vectors": (ctypes.c_int, [c_void_p, i32, c_void_p, c_void_p, c_void_p, i64, i32, i32,
                                               c_void_p, i64, i32]),
+    "hypmi_score_extract": (ctypes.c_int, [c_void_p, i64, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           i64, ctypes.c_float, ctypes.c_float, ctypes.c_int, c_void_p,
+                                           c_void_p, i64, c_void_p, c_void_p]),
     "hypmi_score_hist": (ctypes.c_int, [c_void_p, i64, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p,
                                         i64, ctypes.c_float, ctypes.c_float, ctypes.c_int, c_void_p,
                                         c_void_p, c_void_p]),

@@ -317,6 +317,18 @@ int hypmi_score_hist(const float* S, int64_t lds, int64_t ne, int64_t nt, const 
                      int64_t ldm, float lo, float hi, int nbins, unsigned long long* hist, double* mom,
                      void* stream);
 
+/* Second pass over the same blocks, with the same labels, range and bins: every finite score whose
+ * (class, bin) cell is flagged in want (uint8 [2 x nbins], non-targets first) is appended to the
+ * list of its class: out [2 x cap] floats (non-targets first), count [2] uint64 list lengths (ADDED
+ * to; a count above cap means the list overflowed and the scores beyond cap were dropped).  The order
+ * inside a list is arbitrary.  With the cells that can hold a vertex of the ROC convex hull flagged,
+ * sorting the two lists makes the hull of the first pass exact; with every cell flagged it is
+ * TrialScores.get_tar_non (trial_scores.py:342-357) on the device. */
+int hypmi_score_extract(const float* S, int64_t lds, int64_t ne, int64_t nt, const int32_t* key_e,
+                        const int32_t* key_t, const unsigned char* tar, const unsigned char* non,
+                        int64_t ldm, float lo, float hi, int nbins, const unsigned char* want, float* out,
+                        int64_t cap, unsigned long long* count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

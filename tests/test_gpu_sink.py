@@ -9,6 +9,20 @@ from oracle import plda_ref as O
 pytestmark = pytest.mark.gpu
 
 
+def _strict_vertices(p_miss, p_fa, n_tar, n_non):
+    """Hull vertices as integer (missed targets, accepted non-targets) pairs without the points that
+    lie exactly on the segment between their neighbours.  (The reference pools blocks of equal level
+    with a floating-point comparison of incrementally updated means, which now and then keeps such
+    a point; exact arithmetic never does.  The hull as a curve, EER and DCF are the same.)"""
+    pts = [(int(round(m * n_tar)), int(round(f * n_non))) for m, f in zip(p_miss, p_fa)]
+    keep = [pts[0]]
+    for i in range(1, len(pts) - 1):
+        (m0, f0), (m1, f1), (m2, f2) = keep[-1], pts[i], pts[i + 1]
+        if (m1 - m0) * (f2 - f1) != (m2 - m1) * (f1 - f0):
+            keep.append(pts[i])
+    return keep + [pts[-1]]
+
+
 def _bins(s, lo, hi, nbins):
     scale = np.float32(nbins) / (np.float32(hi) - np.float32(lo))
     f = np.floor((s.astype(np.float32) - np.float32(lo)) * scale)
@@ -137,3 +151,75 @@ def test_snorm_pipeline_streams_into_the_sink():
     assert np.array_equal(a.hist.cpu().numpy(), b.hist.cpu().numpy())
     assert np.allclose(a.mom.cpu().numpy(), b.mom.cpu().numpy(), rtol=1e-12)
     assert int(a.hist.sum()) == 60 * 517
+    # second streamed pass: exact hull without ever holding the matrix
+    second = b.exact_pass()
+    assert be.score_snorm(xt, coh, reduce=second.sink(ke, kt)) is None
+    second.finish()
+    s = full.cpu().numpy().astype(np.float64)
+    is_tar = ke[:, None] == kt[None, :]
+    assert abs(b.eer() - O.compute_eer(s[is_tar], s[~is_tar])) <= 1e-14
+
+
+@pytest.mark.parametrize("ne,nt,nbins,ncls", [(300, 4000, 256, 40), (64, 1500, 32, 8), (1000, 6000, 4096, 200)])
+def test_second_pass_makes_the_hull_exact(ne, nt, nbins, ncls):
+    """Histogram pass, then ONE extraction pass over the bins that can hold a hull vertex: the ROC
+    convex hull, EER and minDCF equal the oracle's on all individual scores."""
+    import torch
+
+    from hyperion_amd.metrics import TrialHistogram
+
+    rng = np.random.RandomState(ne)
+    ke, kt = rng.randint(0, ncls, ne).astype(np.int32), rng.randint(0, ncls, nt).astype(np.int32)
+    is_tar = ke[:, None] == kt[None, :]
+    s = np.where(is_tar, 6 + 4 * rng.randn(ne, nt), -10 + 7 * rng.randn(ne, nt)).astype(np.float32)
+    s[3, 5] = np.nan  # skipped by both passes
+    S = torch.from_numpy(s).cuda()
+    h = TrialHistogram(-45.0, 30.0, nbins).add(S, ke, kt)
+    assert not h.is_exact()
+    coarse = h.eer()
+    second = h.exact_pass()
+    second.add(S[:, :nt // 2], ke, kt[:nt // 2]).add(S[:, nt // 2:], ke, kt[nt // 2:])  # blocks may differ in shape
+    second.finish()
+    assert h.is_exact() and h.exact_pass() is None
+    ok = np.isfinite(s)
+    tar, non = s[is_tar & ok].astype(np.float64), s[~is_tar & ok].astype(np.float64)
+    rm, rf = O.compute_rocch(tar, non)
+    pm, pf = h.rocch()
+    assert _strict_vertices(pm, pf, len(tar), len(non)) == _strict_vertices(rm, rf, len(tar), len(non))
+    assert abs(h.eer() - O.compute_eer(tar, non)) <= 1e-14 and abs(coarse - h.eer()) > 0
+    assert np.allclose(h.min_dcf(0.05), O.compute_min_dcf(tar, non, 0.05), rtol=0, atol=1e-14)
+    # the fraction of scores the second pass had to keep
+    assert sum(second.expect) < 0.6 * ne * nt
+
+
+def test_second_pass_detects_different_scores():
+    import torch
+
+    from hyperion_amd.metrics import TrialHistogram
+
+    rng = np.random.RandomState(0)
+    ke, kt = rng.randint(0, 5, 50).astype(np.int32), rng.randint(0, 5, 700).astype(np.int32)
+    S = torch.from_numpy((4 * rng.randn(50, 700)).astype(np.float32)).cuda()
+    h = TrialHistogram(-20.0, 20.0, 64).add(S, ke, kt)
+    second = h.exact_pass().add(S + 0.5, ke, kt)
+    with pytest.raises(RuntimeError, match="did not see the same scores"):
+        second.finish()
+
+
+def test_full_extraction_is_get_tar_non():
+    """Every cell flagged: the device lists are TrialScores.get_tar_non up to order."""
+    import torch
+
+    from hyperion_amd.metrics.trial_hist import ExactPass, TrialHistogram
+
+    rng = np.random.RandomState(2)
+    tar = rng.rand(40, 900) < 0.05
+    non = (rng.rand(40, 900) < 0.6) & ~tar
+    s = (3 * rng.randn(40, 900)).astype(np.float32)
+    S = torch.from_numpy(s).cuda()
+    h = TrialHistogram(-15.0, 15.0, 128).add(S, tar=tar, non=non)
+    p = ExactPass(h, np.arange(128)).add(S, tar=tar, non=non)
+    n_non, n_tar = (int(c) for c in p.count.cpu())
+    assert (n_non, n_tar) == (int(non.sum()), int(tar.sum()))
+    assert np.array_equal(np.sort(p.out[1, :n_tar].cpu().numpy()), np.sort(s[tar]))
+    assert np.array_equal(np.sort(p.out[0, :n_non].cpu().numpy()), np.sort(s[non]))
