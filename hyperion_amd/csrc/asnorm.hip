@@ -1043,10 +1043,12 @@ int launch_gather(const float* X, int64_t n_rows, int nc, int64_t ldx, const uns
     // in which case the lists are split over blockIdx.y.  Measured at 10k rows x 65536 lists x 300 of
     // 20000 (23.3 ms, 13.7 elements/clk/CU): splitting the lists so that a block of them stays in L2 is
     // slower with every doubling (24.6 ms at 4 blocks ... 45 ms at 64: each block reloads the rows);
-    // six index loads in flight per lane instead of two change nothing; lists without any bank
-    // conflict (all entries equal) still take 20.7 ms.  Neither the index stream nor the LDS banks
-    // bound the walk; what remains is instruction issue and LDS latency (about seven instructions per
-    // pair of gathered values at four waves per SIMD).
+    // six index loads in flight per lane instead of two change nothing; an index stream confined to
+    // 1024 lists (all cache hits) gains 5 %; one VALU instruction less per entry gains nothing; lists
+    // without any bank conflict (all entries equal) take 19.0 ms = 7.6 clocks per ds_read_b64 of a
+    // wave.  The walk is bound by the LDS itself: a random 8-byte gather per lane sustains about
+    // 60 bytes per clock and CU, and four-row workgroups (one 16-byte read per entry, possible for
+    // cohorts up to 10 240) are only 1.17 times faster per element.
     int64_t chunks = 1;
     while (groups * chunks < 1024 && (n_lists + chunks - 1) / chunks > 4 * GS_THREADS) chunks *= 2;
     if (chunks > 65535) chunks = 65535;
