@@ -375,7 +375,12 @@ def main():
         "ms": pro_ms, "bound": "hbm", "achieved": pro_bytes / (pro_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": pro_bytes / (pro_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "algorithmic_bytes": pro_bytes,
-        "note": "matrix-core bound in practice (2 x 512 x 350 flop per vector on the fp32 MFMA)"}
+        "note": "matrix-core bound in practice: see mfma"}
+    if chain is not None:  # u = x A1 (d x d, for the length norm) and x (A1 A2) (d x 2K) on the fp32 matrix cores
+        pro_flops = 2.0 * cfg["d"] * (cfg["d"] + 2 * K) * (n1 + n2)
+        out["prologue_stage"]["mfma"] = {"achieved": pro_flops / (pro_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
+                                         "unit": "TFLOP/s", "frac": pro_flops / (pro_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                         "algorithmic_flops": pro_flops}
     # the same launch against the HBM roof: the score matrix written once plus both operands read once
     # (with 16-bit operands the matrix pipes need less time than the 4 bytes per score need HBM)
     from hyperion_amd import _lib
