@@ -28,10 +28,11 @@ __device__ __forceinline__ float f4_get(const float4& v, int e) {
 }
 
 // smem: SMEM_FLOATS floats, 16-byte aligned.  acc is accumulated into (zero it first for a fresh tile).
+// k_begin (a multiple of 4) skips a leading part of K that the caller knows to be zero in B.
 template <int TM, int TN>
 __device__ __forceinline__ void mainloop(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                          int64_t ldb, int64_t m0, int64_t n0, int64_t M, int64_t N, int K,
-                                         float* smem, f32x16 (&acc)[TM][TN]) {
+                                         float* smem, f32x16 (&acc)[TM][TN], int k_begin = 0) {
     constexpr int BM = Shape<TM, TN>::BM, BN = Shape<TM, TN>::BN;
     float* As = smem;
     float* Bs = smem + BM * LDT;
@@ -57,8 +58,8 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ A, int64_t ld
         }
     };
 
-    fetch(0);
-    for (int k0 = 0; k0 < K; k0 += BK) {
+    fetch(k_begin);
+    for (int k0 = k_begin; k0 < K; k0 += BK) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < BM / 32; ++i)

@@ -24,11 +24,12 @@ struct Segment {
 
 // Last length-normalised segment folded with the PLDA projection (one kernel, see prologue.hip):
 //   u = x A1 + b1 (n_u columns, only its row norm is needed), v = x (A1 A2) + b1 A2 (n_v = 2K columns),
-//   z = sqrt(n_norm) / (|u| + 1e-10) * v + b2.   Wcat = [A1 | A1 A2]^T, [n_u + n_v] x ldw.
+//   z = sqrt(n_norm) / (|u| + 1e-10) * v + b2.   Wcat = [A1 Q | A1 A2]^T, [n_u + n_v] x ldw, with Q
+//   orthogonal and chosen so that A1 Q is lower trapezoidal (|u Q| = |u|); bias_u = b1 Q.
 struct FusedTail {
     bool enabled = false;
     float* Wcat = nullptr;
-    float* bias_u = nullptr;    // b1, n_u entries (nullptr = 0)
+    float* bias_u = nullptr;    // b1 Q, n_u entries (b1 itself without a matrix; nullptr = 0)
     float* bias_vin = nullptr;  // b1 A2, n_v entries (nullptr = 0)
     int64_t ldw = 0;
     int n_u = 0, n_v = 0, d_in = 0;

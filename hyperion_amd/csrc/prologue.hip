@@ -153,8 +153,46 @@ extern "C" int hypmi_plan_create(const hypmi_plan_desc* d, hypmi_plan** out) {
             std::vector<float> wc((size_t)(f.n_u + NV) * f.ldw, 0.f);
             std::vector<float> bv(NV, 0.f);
             std::vector<double> col(dp);
-            for (int j = 0; j < f.n_u; ++j)
-                for (int i = 0; i < dp; ++i) wc[(size_t)j * f.ldw + i] = (float)ls.A[(size_t)i * D1 + j];
+            // Only the row norm of u = x A1 + b1 is used, and u Q has the same norm for any
+            // orthogonal Q.  Householder reflections from the left turn [A1^T | b1^T] into
+            // [R | Q^T b1^T] with R upper trapezoidal: column j of A1 Q = R^T is zero above row j, so
+            // the kernel starts the contraction of column block n0 at k = n0.
+            std::vector<double> bu_rot;
+            if (f.n_u) {
+                const int nc = dp + (ls.b ? 1 : 0);
+                std::vector<double> M((size_t)nc * D1);  // column-major: M[c * D1 + j]
+                for (int i = 0; i < dp; ++i)
+                    for (int j = 0; j < D1; ++j) M[(size_t)i * D1 + j] = ls.A[(size_t)i * D1 + j];
+                if (ls.b)
+                    for (int j = 0; j < D1; ++j) M[(size_t)dp * D1 + j] = ls.b[j];
+                std::vector<double> hv(D1);
+                const int steps = D1 - 1 < dp ? D1 - 1 : dp;
+                for (int c = 0; c < steps; ++c) {
+                    double* colc = &M[(size_t)c * D1];
+                    double nrm = 0.0;
+                    for (int j = c; j < D1; ++j) nrm += colc[j] * colc[j];
+                    nrm = sqrt(nrm);
+                    if (nrm == 0.0) continue;
+                    const double alpha = colc[c] > 0 ? -nrm : nrm;
+                    double vnorm2 = 0.0;
+                    for (int j = c; j < D1; ++j) {
+                        hv[j] = colc[j] - (j == c ? alpha : 0.0);
+                        vnorm2 += hv[j] * hv[j];
+                    }
+                    if (vnorm2 == 0.0) continue;
+                    for (int cc = c; cc < nc; ++cc) {
+                        double* col2 = &M[(size_t)cc * D1];
+                        double dot = 0.0;
+                        for (int j = c; j < D1; ++j) dot += hv[j] * col2[j];
+                        const double t = 2.0 * dot / vnorm2;
+                        for (int j = c; j < D1; ++j) col2[j] -= t * hv[j];
+                    }
+                    for (int j = c + 1; j < D1; ++j) colc[j] = 0.0;  // exact zeros below the diagonal
+                }
+                for (int j = 0; j < f.n_u; ++j)
+                    for (int i = 0; i < dp; ++i) wc[(size_t)j * f.ldw + i] = (float)M[(size_t)i * D1 + j];
+                if (ls.b) bu_rot.assign(&M[(size_t)dp * D1], &M[(size_t)dp * D1] + D1);
+            }
             for (int j = 0; j < NV; ++j) {
                 // column j of A1 A2 (A1 = identity when the segment has no matrix)
                 double bacc = 0.0;
@@ -174,7 +212,9 @@ extern "C" int hypmi_plan_create(const hypmi_plan_desc* d, hypmi_plan** out) {
             }
             rc = to_device(wc, &f.Wcat);
             if (rc == HYPMI_OK && ls.b) {
-                std::vector<float> bu(ls.b, ls.b + D1);
+                // rotated with the matrix when there is one; the bias itself for the identity
+                std::vector<float> bu(D1);
+                for (int j = 0; j < D1; ++j) bu[j] = (float)(f.n_u ? bu_rot[j] : ls.b[j]);
                 rc = to_device(bu, &f.bias_u);
                 if (rc == HYPMI_OK) rc = to_device(bv, &f.bias_vin);
             }
@@ -274,7 +314,8 @@ __global__ __launch_bounds__(256) void prologue_fused_kernel(
         for (int e = 0; e < 16; ++e) ss[i][e] = 0.f;
     for (int n0 = 0; n0 < n_u; n0 += 128) {
         gemm_tile::zero<TM, 2>(acc);
-        gemm_tile::mainloop<TM, 2>(x, ldx, Wcat, ldw, m0, n0, n, n_u, d_in, smem, acc);
+        // rows of Wcat from n0 on are zero in their first n0 entries (see plan_create)
+        gemm_tile::mainloop<TM, 2>(x, ldx, Wcat, ldw, m0, n0, n, n_u, d_in, smem, acc, n0);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + gemm_tile::col_of<2>(j);
