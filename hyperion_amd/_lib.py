@@ -119,6 +119,12 @@ SIGNATURES = {
                                         c_void_p, c_void_p, i64, c_void_p]),
     "hypmi_gram_f64": (ctypes.c_int, [c_void_p, i64, i64, ctypes.c_int, c_void_p, c_void_p, i64, c_void_p,
                                       c_void_p]),
+    "hypmi_pool_rows_f64": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, c_void_p, c_void_p, i64, c_void_p,
+                                           c_void_p, i64, c_void_p]),
+    "hypmi_gemm_nt_f64": (ctypes.c_int, [c_void_p, i64, i64, c_void_p, i64, i64, ctypes.c_int, c_void_p,
+                                         c_void_p, i64, c_void_p]),
+    "hypmi_splda_posterior": (ctypes.c_int, [c_void_p, i64, i64, ctypes.c_int, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_void_p]),
     "hypmi_ark_probe": (ctypes.c_int, [ctypes.c_char_p, i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hypmi_ark_read_vectors": (ctypes.c_int, [c_void_p, i32, c_void_p, c_void_p, c_void_p, i64, i32, i32,
                                               c_void_p, i64, i32]),

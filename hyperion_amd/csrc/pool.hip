@@ -10,14 +10,16 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-// out[g,:] = sum (or mean) of x[order[r],:] for r in [offsets[g], offsets[g+1]).
-// Rows are added in list order with a double accumulator, so the result does not depend on
-// scheduling.  An empty class gives 0 (sum) or NaN (mean = 0/0), as dividing F by N = 0 does.
-__global__ __launch_bounds__(256) void pool_rows_kernel(const float* __restrict__ x, int64_t ldx, int d,
+// out[g,:] = sum (or mean) of w[order[r]] x[order[r],:] for r in [offsets[g], offsets[g+1]) (w = 1
+// without weights).  Rows are added in list order with a double accumulator, so the result does not
+// depend on scheduling.  An empty class gives 0 (sum) or NaN (mean = 0/0), as dividing F by N = 0 does.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void pool_rows_kernel(const TI* __restrict__ x, int64_t ldx, int d,
                                                         const int32_t* __restrict__ order,
                                                         const int64_t* __restrict__ offsets,
                                                         int64_t n_groups, int mean,
-                                                        float* __restrict__ out, int64_t ldo,
+                                                        const double* __restrict__ w,
+                                                        TO* __restrict__ out, int64_t ldo,
                                                         float* __restrict__ counts) {
     const int lane = threadIdx.x & 63;
     const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -28,17 +30,19 @@ __global__ __launch_bounds__(256) void pool_rows_kernel(const float* __restrict_
     for (int k0 = 0; k0 < d; k0 += 256) {
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
         for (int64_t r = r0; r < r1; ++r) {
-            const float* row = x + (int64_t)order[r] * ldx;
+            const int64_t src = order[r];
+            const TI* row = x + src * ldx;
+            const double ws = w ? w[src] : 1.0;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int k = k0 + 64 * u + lane;
-                if (k < d) acc[u] += (double)row[k];
+                if (k < d) acc[u] += ws * (double)row[k];
             }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k = k0 + 64 * u + lane;
-            if (k < d) out[g * ldo + k] = (float)(acc[u] * inv);
+            if (k < d) out[g * ldo + k] = (TO)(acc[u] * inv);
         }
     }
 }
@@ -106,9 +110,22 @@ extern "C" int hypmi_pool_rows(const float* x, int64_t ldx, int d, const int32_t
     HYPMI_REQUIRE(x && order && offsets && out, "pool_rows: null pointer");
     HYPMI_REQUIRE(d > 0 && ldx >= d && ldo >= d && n_groups >= 0, "pool_rows: bad shape");
     if (n_groups == 0) return HYPMI_OK;
-    hipLaunchKernelGGL(pool_rows_kernel, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), x, ldx, d, order, offsets, n_groups, mean, out,
-                       ldo, counts);
+    hipLaunchKernelGGL((pool_rows_kernel<float, float>), dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, ldx, d, order, offsets, n_groups, mean,
+                       (const double*)nullptr, out, ldo, counts);
+    HYPMI_HIP(hipGetLastError());
+    return HYPMI_OK;
+}
+
+extern "C" int hypmi_pool_rows_f64(const double* x, int64_t ldx, int d, const int32_t* order,
+                                   const int64_t* offsets, int64_t n_groups, const double* w, double* out,
+                                   int64_t ldo, void* stream) {
+    HYPMI_REQUIRE(x && order && offsets && out, "pool_rows_f64: null pointer");
+    HYPMI_REQUIRE(d > 0 && ldx >= d && ldo >= d && n_groups >= 0, "pool_rows_f64: bad shape");
+    if (n_groups == 0) return HYPMI_OK;
+    hipLaunchKernelGGL((pool_rows_kernel<double, double>), dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, ldx, d, order, offsets, n_groups, 0, w, out, ldo,
+                       (float*)nullptr);
     HYPMI_HIP(hipGetLastError());
     return HYPMI_OK;
 }

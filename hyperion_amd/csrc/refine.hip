@@ -216,6 +216,15 @@ __global__ __launch_bounds__(256) void refine_scores_kernel(float* __restrict__ 
 
 }  // namespace
 
+extern "C" int hypmi_gemm_nt_f64(const double* A, int64_t m, int64_t lda, const double* B, int64_t n,
+                                 int64_t ldb, int k, const double* bias, double* C, int64_t ldc,
+                                 void* stream_) {
+    HYPMI_REQUIRE(m >= 0 && n >= 0 && k > 0 && lda >= k && ldb >= k && ldc >= n, "gemm_nt_f64: bad shape");
+    if (m == 0 || n == 0) return HYPMI_OK;
+    HYPMI_REQUIRE(A && B && C, "gemm_nt_f64: null pointer");
+    return launch_gemm_f64(A, lda, B, ldb, bias, C, ldc, m, n, k, static_cast<hipStream_t>(stream_));
+}
+
 extern "C" int64_t hypmi_prologue_f64_workspace_bytes(const hypmi_plan* p, int64_t n) {
     if (!p || n <= 0) return 0;
     const int64_t rows = n < F64_CHUNK_ROWS ? n : F64_CHUNK_ROWS;

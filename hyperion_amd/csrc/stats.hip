@@ -11,6 +11,8 @@
 // MFMAs of the current one run, and the block is added to C with float64 atomics at the end.  Only
 // blocks on or above the diagonal are computed; off-diagonal blocks are added to both halves.
 // A wave that ends early returns before anything collective: the kernel has no barrier.
+//
+// The file also holds the per-class posterior step of SPLDA training (splda_posterior_kernel).
 #include "common.h"
 
 namespace {
@@ -120,7 +122,57 @@ __global__ __launch_bounds__(256) void colsum_f64_kernel(const double* __restric
     if (r1 > r0) atomicAdd(&F[c], s);
 }
 
+// Latent posterior of the two-covariance model in the eigenbasis of V W V^T = Q diag(lam) Q^T, where
+// the posterior precision I + N_i V W V^T of every class is diagonal:
+//   T[i, j] <- T[i, j] / (1 + N_i lam_j)                      (posterior mean, eigenbasis)
+//   logpy_i  = -K/2 log(2 pi) + 1/2 (sum_j log(1 + N_i lam_j) - sum_j T_new[i, j] T_old[i, j])
+// A wave walks rows with a grid stride and adds its share of sum_i logpy_i with one atomic.
+__global__ __launch_bounds__(256) void splda_posterior_kernel(double* __restrict__ T, int64_t ldt, int64_t m,
+                                                              int K, const double* __restrict__ N,
+                                                              const double* __restrict__ lam,
+                                                              double* __restrict__ logpy,
+                                                              double* __restrict__ logpy_sum) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t waves = (int64_t)gridDim.x * 4;
+    const double c0 = -0.5 * K * 1.8378770664093454835606594728112;  // log(2 pi)
+    double total = 0.0;
+    for (int64_t row = wave; row < m; row += waves) {
+        const double ni = N[row];
+        double* t = T + row * ldt;
+        double part = 0.0;
+        for (int j = lane; j < K; j += 64) {
+            const double p = 1.0 + ni * lam[j];
+            const double g = t[j];
+            const double y = g / p;
+            t[j] = y;
+            part += log(p) - y * g;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        const double lp = c0 + 0.5 * part;
+        if (lane == 0 && logpy) logpy[row] = lp;
+        total += lp;
+    }
+    if (lane == 0 && logpy_sum && total != 0.0) atomicAdd(logpy_sum, total);
+}
+
 }  // namespace
+
+extern "C" int hypmi_splda_posterior(double* T, int64_t m, int64_t ldt, int K, const double* N,
+                                     const double* lam, double* logpy, double* logpy_sum, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HYPMI_REQUIRE(m >= 0 && K > 0 && ldt >= K, "splda_posterior: bad shape");
+    if (logpy_sum) HYPMI_HIP(hipMemsetAsync(logpy_sum, 0, sizeof(double), stream));
+    if (m == 0) return HYPMI_OK;
+    HYPMI_REQUIRE(T && N && lam, "splda_posterior: null pointer");
+    int64_t blocks = (m + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splda_posterior_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, T, ldt, m, K, N, lam,
+                       logpy, logpy_sum);
+    HYPMI_HIP(hipGetLastError());
+    return HYPMI_OK;
+}
 
 extern "C" int hypmi_gram_f64(const double* X, int64_t n, int64_t ldx, int d, const double* w, double* C,
                               int64_t ldc, double* F, void* stream_) {

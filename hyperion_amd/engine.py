@@ -77,17 +77,49 @@ def upload64(x):
     return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).cuda()
 
 
+def small_host_algebra(fn):
+    """Decorator for host code whose LAPACK / BLAS calls work on y_dim- and x_dim-sized matrices:
+    they run on one thread.  Waking a 16-thread pool costs ~10 ms per call on a many-core host, a
+    hundred times the call itself (measured: 131 ms -> 5 ms per training epoch)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        try:
+            from threadpoolctl import threadpool_limits
+        except ImportError:
+            return fn(*args, **kwargs)
+        with threadpool_limits(limits=1, user_api="blas"):
+            return fn(*args, **kwargs)
+
+    return wrapped
+
+
+def _rows64(x):
+    """Device float64 rows with unit column stride (a column slice of a wider buffer is taken as it
+    is, anything else goes through upload64)."""
+    torch = require_gpu()
+    if (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float64 and x.dim() == 2
+            and (x.shape[1] == 1 or x.stride(1) == 1) and (x.shape[0] <= 1 or x.stride(0) >= x.shape[1])):
+        return x
+    return upload64(x)
+
+
+def _vec64(w, n):
+    torch = require_gpu()
+    W = w if isinstance(w, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(w, dtype=np.float64))
+    W = W.to(device="cuda", dtype=torch.float64).contiguous()
+    assert W.shape == (n,)
+    return W
+
+
 def gram64(x, w=None):
     """(sum_s w_s x_s x_s^T, sum_s w_s x_s) as device float64 tensors [d, d] and [d]; x numpy or
     device [n, d], w optional row weights [n]."""
     torch = require_gpu()
-    X = upload64(x)
+    X = _rows64(x)
     n, d = X.shape
-    W = None
-    if w is not None:
-        W = (w if isinstance(w, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(w, dtype=np.float64)))
-        W = W.to(device="cuda", dtype=torch.float64).contiguous()
-        assert W.shape == (n,)
+    W = None if w is None else _vec64(w, n)
     C = torch.empty((d, d), dtype=torch.float64, device="cuda")
     F = torch.empty((d,), dtype=torch.float64, device="cuda")
     _lib.check(_lib.load().hypmi_gram_f64(_ptr(X), n, X.stride(0) if n > 1 else d, d,
@@ -95,6 +127,56 @@ def gram64(x, w=None):
                                           stream_ptr()))
     # the two halves are summed by different workgroups in different orders: make them one matrix
     return 0.5 * (C + C.T), F
+
+
+def gemm64(a, b, bias=None, out=None):
+    """a [m, k] @ b[n, k]^T (+ bias [n]) in float64 on the device; `out` may be a column slice of a
+    wider float64 buffer."""
+    torch = require_gpu()
+    A, B = _rows64(a), _rows64(b)
+    m, k = A.shape
+    n = B.shape[0]
+    assert B.shape[1] == k
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float64, device="cuda")
+    assert out.shape == (m, n) and out.dtype == torch.float64 and (n == 1 or out.stride(1) == 1)
+    bv = None if bias is None else _vec64(bias, n)
+    _lib.check(_lib.load().hypmi_gemm_nt_f64(_ptr(A), m, A.stride(0) if m > 1 else k, _ptr(B), n,
+                                             B.stride(0) if n > 1 else k, k,
+                                             ctypes.c_void_p(0) if bv is None else _ptr(bv), _ptr(out),
+                                             out.stride(0) if m > 1 else n, stream_ptr()))
+    return out
+
+
+def pool64(x, order, offsets, w=None):
+    """Float64 class sums: out[g] = sum of w_r x_r over rows order[offsets[g]:offsets[g + 1]]."""
+    torch = require_gpu()
+    X = _rows64(x)
+    n, d = X.shape
+    C = len(offsets) - 1
+    out = torch.zeros((C, d), dtype=torch.float64, device="cuda")
+    if C and n:
+        o_dev = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int32)).cuda()
+        f_dev = torch.from_numpy(np.ascontiguousarray(offsets, dtype=np.int64)).cuda()
+        W = None if w is None else _vec64(w, n)
+        _lib.check(_lib.load().hypmi_pool_rows_f64(_ptr(X), X.stride(0) if n > 1 else d, d, _ptr(o_dev),
+                                                   _ptr(f_dev), C, ctypes.c_void_p(0) if W is None else _ptr(W),
+                                                   _ptr(out), d, stream_ptr()))
+    return out
+
+
+def splda_posterior(T, N, lam):
+    """In place T[i, j] /= 1 + N_i lam_j on a device float64 [m, K] buffer; returns the per-class
+    log-normalisers (device [m]) and their sum (device scalar), see hypmi_splda_posterior."""
+    torch = require_gpu()
+    m, K = T.shape
+    assert T.dtype == torch.float64 and T.is_cuda and (K == 1 or T.stride(1) == 1)
+    Nd, ld = _vec64(N, m), _vec64(lam, K)
+    logpy = torch.empty((m,), dtype=torch.float64, device="cuda")
+    total = torch.zeros((1,), dtype=torch.float64, device="cuda")
+    _lib.check(_lib.load().hypmi_splda_posterior(_ptr(T), m, T.stride(0) if m > 1 else K, K, _ptr(Nd),
+                                                 _ptr(ld), _ptr(logpy), _ptr(total), stream_ptr()))
+    return logpy, total
 
 
 # fp32 error model of one score: |err| <= ERR_COEFF * (|g1| |g2| + |q1| + |q2|), 8 units of 2^-24

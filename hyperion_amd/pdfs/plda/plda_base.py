@@ -1,5 +1,5 @@
-"""Common scoring machinery of the PLDA models (host API of hyperion/pdfs/plda/plda_base.py,
-executed on the GPU).  Training (fit / E-step / M-step) is outside this package."""
+"""Common machinery of the PLDA models (host API of hyperion/pdfs/plda/plda_base.py, executed on
+the GPU): scoring, sufficient statistics and the EM training loop."""
 import numpy as np
 
 from ... import _lib, engine
@@ -46,6 +46,39 @@ def pool_rows(x_dev, class_ids, mean):
                                        engine._ptr(f_dev), C, int(bool(mean)), engine._ptr(out), ld,
                                        None, engine.stream_ptr()))
     return out[:, :d], counts
+
+
+class ClassStats:
+    """Sufficient statistics of a labelled training set, resident on the device for the epochs of a
+    training run: N [M] class counts (host float64), F [M, d] class sums (device float64), S [d, d]
+    second-order statistic (device float64).  `ClassStats.of(D)` takes a host (N, F, S) tuple as it is
+    passed around by the reference's API."""
+
+    def __init__(self, N, F, S):
+        self.N = np.asarray(N, dtype=np.float64)
+        self.F = F
+        self.S = S
+        self._S_host = None
+
+    @classmethod
+    def of(cls, D):
+        if isinstance(D, cls):
+            return D
+        N, F, S = D
+        return cls(N, engine.upload64(F), None if S is None else engine.upload64(S))
+
+    @property
+    def S_host(self):
+        if self._S_host is None and self.S is not None:
+            self._S_host = self.S.cpu().numpy()
+        return self._S_host
+
+    def host(self):
+        return (self.N.astype(float_cpu()), self.F.cpu().numpy().astype(float_cpu()),
+                None if self.S is None else self.S_host.astype(float_cpu()))
+
+    def __iter__(self):  # N, F, S = D
+        return iter(self.host())
 
 
 class PLDABase(HypModel):
@@ -131,28 +164,104 @@ class PLDABase(HypModel):
 
     # ---- sufficient statistics ----------------------------------------------------------------
     @staticmethod
-    def compute_stats_hard(x, class_ids, sample_weight=None, scale_factor=None):
-        """(N, F, S) per class for classes 0..max(id) (plda_base.py:249-274): counts, per-class
-        sums (fp32 segmented sums on the GPU) and the global second-order statistic S = x^T x
-        (float64 matrix cores).  With sample_weight w: N = sum w, F = sum w x, S = (w x)^T x."""
-        torch = engine.require_gpu()
-        xd = engine.upload(x)
+    def _stats_hard_device(x, class_ids, sample_weight=None, scale_factor=None):
+        """compute_stats_hard with everything left on the device: a ClassStats."""
+        X = engine.upload64(x)
+        order, offsets, counts = _group_index(class_ids)
+        if order.shape[0] != X.shape[0]:
+            raise ValueError("%d class ids for %d rows" % (order.shape[0], X.shape[0]))
         if sample_weight is not None:
-            w = torch.from_numpy(np.ascontiguousarray(sample_weight, dtype=np.float32)).to(xd.device)
-            F_dev, _ = pool_rows(xd * w[:, None], class_ids, mean=False)
             ids = np.asarray(class_ids).astype(np.int64).reshape(-1)
             N = np.bincount(ids, weights=np.asarray(sample_weight, dtype=np.float64),
-                            minlength=F_dev.shape[0]).astype(float_cpu())
+                            minlength=len(counts)).astype(np.float64)
         else:
-            F_dev, counts = pool_rows(xd, class_ids, mean=False)
-            N = counts.astype(float_cpu())
-        F = engine.to_host(F_dev, float_cpu())
-        S = engine.gram64(x, sample_weight)[0].cpu().numpy().astype(float_cpu())
+            N = counts.astype(np.float64)
+        F = engine.pool64(X, order, offsets, sample_weight)
+        S = engine.gram64(X, sample_weight)[0]
         if scale_factor is not None:
-            N = N * scale_factor
-            F = F * scale_factor
-            S = S * scale_factor
-        return N, F, S
+            N, F, S = N * scale_factor, F * scale_factor, S * scale_factor
+        return ClassStats(N, F, S)
+
+    @staticmethod
+    def compute_stats_hard(x, class_ids, sample_weight=None, scale_factor=None):
+        """(N, F, S) per class for classes 0..max(id) (plda_base.py:249-274): counts, per-class
+        sums (float64 segmented sums on the GPU) and the global second-order statistic S = x^T x
+        (float64 matrix cores).  With sample_weight w: N = sum w, F = sum w x, S = (w x)^T x."""
+        return PLDABase._stats_hard_device(x, class_ids, sample_weight, scale_factor).host()
+
+    @staticmethod
+    def compute_stats_soft(x, p_theta, sample_weight=None, scal_factor=None):
+        """Statistics from class posteriors p_theta [n, C] (plda_base.py:236-246): N = sum_s p,
+        F = p^T x, S = x^T diag(sum_c p) x.  (The reference scales the caller's p_theta in place
+        when scal_factor is given; here it is left alone.)"""
+        return PLDABase._stats_soft_device(x, p_theta, sample_weight, scal_factor).host()
+
+    @staticmethod
+    def _stats_soft_device(x, p_theta, sample_weight=None, scal_factor=None):
+        X = engine.upload64(x)
+        P = engine.upload64(p_theta)
+        if sample_weight is not None:
+            P = P * engine.upload64(np.asarray(sample_weight, dtype=np.float64)[:, None])
+        if scal_factor is not None:
+            P = P * scal_factor
+        N = P.sum(dim=0).cpu().numpy()
+        F = engine.gemm64(P.t().contiguous(), X.t().contiguous())  # [C, n] [d, n]^T
+        S = engine.gram64(X, P.sum(dim=1))[0]
+        return ClassStats(N, F, S)
+
+    # ---- training ------------------------------------------------------------------------------
+    def initialize(self, D):
+        raise NotImplementedError
+
+    def Estep(self, D):
+        raise NotImplementedError
+
+    def elbo(self, stats):
+        raise NotImplementedError
+
+    def MstepML(self, stats):
+        raise NotImplementedError
+
+    def MstepMD(self, stats):
+        raise NotImplementedError
+
+    def _train_stats(self, x, class_ids, ptheta, sample_weight):
+        assert not (class_ids is None and ptheta is None)
+        if class_ids is None:
+            return self._stats_soft_device(x, ptheta)
+        return self._stats_hard_device(x, class_ids)
+
+    @engine.small_host_algebra
+    def fit(self, x, class_ids=None, ptheta=None, sample_weight=None, x_val=None, class_ids_val=None,
+            ptheta_val=None, sample_weight_val=None, epochs=20, ml_md="ml+md", md_epochs=None):
+        """EM training (plda_base.py:34-88): statistics once, then per epoch an E-step on the device
+        over the class statistics, the ELBO, and the maximum-likelihood and / or minimum-divergence
+        M-steps on the small accumulators.  Returns (elbo, elbo / N) per epoch, and the same for the
+        validation set when one is given.  As in the reference, sample weights are accepted and not
+        used (plda_base.py:56)."""
+        use_ml = ml_md != "md"
+        use_md = ml_md != "ml"
+        D = self._train_stats(x, class_ids, ptheta, sample_weight)
+        D_val = None
+        if x_val is not None:
+            D_val = self._train_stats(x_val, class_ids_val, ptheta_val, sample_weight_val)
+        if not self.is_init:
+            self.initialize(D)
+        elbo = np.zeros((epochs,), dtype=float_cpu())
+        elbo_val = np.zeros((epochs,), dtype=float_cpu())
+        for epoch in range(epochs):
+            stats = self.Estep(D)
+            elbo[epoch] = self.elbo(stats)
+            if D_val is not None:
+                elbo_val[epoch] = self.elbo(self.Estep(D_val))
+            if use_ml:
+                self.MstepML(stats)
+            if use_md and (md_epochs is None or epoch in md_epochs):
+                self.MstepMD(stats)
+        elbo_norm = elbo / np.sum(D.N)
+        if D_val is None:
+            return elbo, elbo_norm
+        return elbo, elbo_norm, elbo_val, elbo_val / np.sum(D_val.N)
 
     # ---- N vs M -----------------------------------------------------------------------------
     def _pooled_mean(self, x, ids):

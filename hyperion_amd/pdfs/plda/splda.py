@@ -1,7 +1,9 @@
 import numpy as np
 
 from ... import fold
-from .plda_base import PLDABase
+from ... import engine
+from ...hyp_defs import float_cpu
+from .plda_base import ClassStats, PLDABase
 
 
 class SPLDA(PLDABase):
@@ -75,6 +77,159 @@ class SPLDA(PLDABase):
         W_p = sla.cho_solve(sla.cho_factor(Sw_p), np.eye(Sw_p.shape[0]))
         return SPLDA(mu=mu @ T, V=np.asarray(self.V, dtype=np.float64) @ T, W=0.5 * (W_p + W_p.T),
                      fullcov_W=True)
+
+    # ---- training (hyperion/pdfs/plda/splda.py:50-242) ----------------------------------------
+    def _W_full(self):
+        W = np.asarray(self.W, dtype=np.float64)
+        return np.diag(W) if W.ndim == 1 else W
+
+    @engine.small_host_algebra
+    def initialize(self, D):
+        """First model from the statistics (splda.py:50-71): mu = mean of the class means, V = the
+        leading principal directions of the class means scaled by their singular values, W from
+        the scatter that the class means leave.  The singular vectors come from the d x d Gram
+        matrix of the centred class means (device) instead of an SVD of the [classes, d] matrix:
+        the rows of V can differ from the reference's in sign, which no score, posterior
+        covariance or ELBO depends on."""
+        from scipy import linalg as sla
+
+        D = ClassStats.of(D)
+        torch = engine.require_gpu()
+        N = D.N
+        self.x_dim = D.F.shape[1]
+        Nd = torch.from_numpy(N).cuda()
+        means = D.F / Nd[:, None]
+        mu = means.mean(dim=0)
+        G = engine.gram64(means - mu)[0].cpu().numpy()
+        ev, U = sla.eigh(G)
+        ev, U = ev[::-1][:self.y_dim], U[:, ::-1][:, :self.y_dim]
+        V = np.sqrt(np.maximum(ev, 0.0))[:, None] * U.T
+        C = (D.S_host - engine.gram64(means, N)[0].cpu().numpy()) / np.sum(N)
+        if self.fullcov_W:
+            W = sla.cho_solve(sla.cho_factor(C), np.eye(C.shape[0]))
+        else:
+            W = 1 / np.diag(C)
+        self.mu, self.V, self.W = mu.cpu().numpy(), V, W
+
+    def _posterior(self, D, want_logpy):
+        """Device posterior means of the class factors.  V W V^T = Q diag(lam) Q^T makes every
+        L_i = I + N_i V W V^T diagonal in the basis Q, so the reference's loop over distinct
+        counts with a Cholesky each (splda.py:112-142) is two products and one scaling pass.
+        Returns (Z, y, logpy, logpy_sum, lam, Q): Z = [F | y] as one device buffer."""
+        from scipy import linalg as sla
+
+        torch = engine.require_gpu()
+        V = np.asarray(self.V, dtype=np.float64)
+        mu = np.asarray(self.mu, dtype=np.float64)
+        WV = self._W_full() @ V.T
+        VV = V @ WV
+        lam, Q = sla.eigh(0.5 * (VV + VV.T))
+        lam = np.maximum(lam, 0.0)
+        B = WV @ Q  # [d, K]
+        M, d = D.F.shape
+        K = V.shape[0]
+        Z = torch.empty((M, d + K), dtype=torch.float64, device="cuda")
+        Z[:, :d] = D.F
+        T = engine.gemm64(D.F, np.ascontiguousarray(B.T), bias=-(mu @ B))  # (F - mu) W V^T Q
+        logpy, total = engine.splda_posterior(T, D.N, lam)
+        y = engine.gemm64(T, Q, out=Z[:, d:])  # back to the model's basis
+        return Z, y, (logpy if want_logpy else None), total, lam, Q
+
+    @staticmethod
+    def _posterior_cov_sums(N, lam, Q):
+        """sum_i L_i^-1 and sum_i N_i L_i^-1 (Py and Ry of splda.py:144-146) from the distinct counts."""
+        uniq, cnt = np.unique(N, return_counts=True)
+        inv = 1.0 / (1.0 + uniq[:, None] * lam[None, :])
+        Py = (Q * (cnt[:, None] * inv).sum(axis=0)) @ Q.T
+        Ry = (Q * ((cnt * uniq)[:, None] * inv).sum(axis=0)) @ Q.T
+        return Ry, Py
+
+    @engine.small_host_algebra
+    def compute_py_g_x(self, D, return_cov=False, return_logpy_0=False, return_acc=False):
+        """Posterior of the speaker factor of every class given its statistics (splda.py:73-158):
+        y [M, y_dim] and on request the posterior covariances [M, y_dim, y_dim], the log
+        normalisers logpy [M], and the accumulators (Ry, Py).  Host arrays out."""
+        D = ClassStats.of(D)
+        _, y, logpy, _, lam, Q = self._posterior(D, return_logpy_0)
+        r = [y.cpu().numpy().astype(float_cpu())]
+        if return_cov:
+            uniq, inverse = np.unique(D.N, return_inverse=True)
+            cov = np.einsum("ak,uk,bk->uab", Q, 1.0 / (1.0 + uniq[:, None] * lam[None, :]), Q)
+            r.append(cov[inverse].astype(float_cpu()))
+        if return_logpy_0:
+            r.append(logpy.cpu().numpy().astype(float_cpu()))
+        if return_acc:
+            r += list(self._posterior_cov_sums(D.N, lam, Q))
+        return r[0] if len(r) == 1 else tuple(r)
+
+    @engine.small_host_algebra
+    def Estep(self, D):
+        """Accumulators of one EM epoch (splda.py:160-179):
+        (N_tot, M, F_tot, S, sum logpy, sum y, sum N y, Ry, Cy = F^T y, Py).  The products over the
+        classes are two Gram passes on the device, over [F | y] and over y weighted by N."""
+        D = ClassStats.of(D)
+        Z, y, _, total, lam, Q = self._posterior(D, False)
+        d = D.F.shape[1]
+        G, colsum = engine.gram64(Z)
+        G, colsum = G.cpu().numpy(), colsum.cpu().numpy()
+        GN, Ry1 = engine.gram64(y, D.N)
+        Ry, Py = self._posterior_cov_sums(D.N, lam, Q)
+        Ry = Ry + GN.cpu().numpy()
+        Py = Py + G[d:, d:]
+        return (np.sum(D.N), D.F.shape[0], colsum[:d], D.S_host, float(total.item()), colsum[d:],
+                Ry1.cpu().numpy(), Ry, G[:d, d:], Py)
+
+    @engine.small_host_algebra
+    def elbo(self, stats):
+        """Evidence lower bound from the E-step accumulators (splda.py:181-196)."""
+        N, M, F, S, logpy_x = stats[:5]
+        W, mu = self._W_full(), np.asarray(self.mu, dtype=np.float64)
+        logW = 2.0 * np.sum(np.log(np.diag(np.linalg.cholesky(W))))
+        Fmu = np.outer(F, mu)
+        Shat = S - Fmu - Fmu.T + N * np.outer(mu, mu)
+        logpx_y = 0.5 * (-N * self.x_dim * np.log(2 * np.pi) + N * logW - np.sum(W * Shat))
+        return logpx_y - 0.5 * M * self.y_dim * np.log(2 * np.pi) - logpy_x
+
+    @engine.small_host_algebra
+    def MstepML(self, stats):
+        """Maximum-likelihood update of (V, mu) and W from the accumulators (splda.py:198-230);
+        host algebra on y_dim- and x_dim-sized matrices."""
+        from scipy import linalg as sla
+
+        N, M, F, S, _, y_acc, Ry1, Ry, Cy, Py = stats
+        Rytilde = np.block([[Ry, Ry1[:, None]], [Ry1[None, :], np.array([[N]])]])
+        Cytilde = np.hstack((Cy, F[:, None]))
+        joint = self.update_mu and self.update_V
+        if self.update_mu and not self.update_V:
+            self.mu = (F - Ry1 @ self.V) / N
+        if self.update_V and not self.update_mu:
+            self.V = sla.cho_solve(sla.cho_factor(Ry), Cy.T - np.outer(Ry1, self.mu))
+        if joint:
+            Vtilde = sla.cho_solve(sla.cho_factor(Rytilde), Cytilde.T)
+            self.V, self.mu = Vtilde[:-1, :], Vtilde[-1, :]
+        if self.update_W:
+            if joint:
+                iW = (S - Cy @ self.V - np.outer(F, self.mu)) / N
+            else:
+                Vtilde = np.vstack((self.V, self.mu))
+                CVt = Cytilde @ Vtilde
+                iW = (S - CVt - CVt.T + Vtilde.T @ Rytilde @ Vtilde) / N
+            if self.fullcov_W:
+                self.W = sla.cho_solve(sla.cho_factor(iW), np.eye(iW.shape[0]))
+            else:
+                self.W = np.diag(1 / np.diag(iW))
+
+    @engine.small_host_algebra
+    def MstepMD(self, stats):
+        """Minimum-divergence update: the factor prior is moved back to N(0, I) (splda.py:232-242)."""
+        from scipy import linalg as sla
+
+        N, M, F, S, _, y_acc, Ry1, Ry, Cy, Py = stats
+        mu_y = y_acc / M
+        if self.update_mu:
+            self.mu = self.mu + mu_y @ self.V
+        if self.update_V:
+            self.V = sla.cholesky(Py / M - np.outer(mu_y, mu_y), lower=False) @ self.V
 
     def get_config(self):
         config = {"update_W": self.update_W, "update_V": self.update_V, "fullcov_W": self.fullcov_W}

@@ -274,6 +274,27 @@ int hypmi_norm_apply(const float* S, int64_t lds, int64_t ne, int64_t nt, const 
 int hypmi_gram_f64(const double* X, int64_t n, int64_t ldx, int d, const double* w, double* C,
                    int64_t ldc, double* F, void* stream);
 
+/* Float64 class sums for training: out[g] = sum over the rows of class g of w_r x_r (w NULL: 1), rows
+ * listed by order / offsets as in hypmi_pool_rows.  F of PLDABase.compute_stats_hard
+ * (hyperion/pdfs/plda/plda_base.py:258-266) at the reference's precision. */
+int hypmi_pool_rows_f64(const double* x, int64_t ldx, int d, const int32_t* order, const int64_t* offsets,
+                        int64_t n_groups, const double* w, double* out, int64_t ldo, void* stream);
+
+/* C[m x n] = A[m x k] B[n x k]^T + bias[n] in float64 on the f64 matrix cores (bias may be NULL).
+ * Training-side products over the class statistics: gamma = (F - mu) W V^T
+ * (hyperion/pdfs/plda/splda.py:77-93) and the change of basis of the posterior means. */
+int hypmi_gemm_nt_f64(const double* A, int64_t m, int64_t lda, const double* B, int64_t n, int64_t ldb,
+                      int k, const double* bias, double* C, int64_t ldc, void* stream);
+
+/* Posterior of the SPLDA speaker factors given class statistics, in the eigenbasis of
+ * V W V^T = Q diag(lam) Q^T (there L_i = I + N_i V W V^T is diagonal for every class at once, so the
+ * loop over the distinct N_i with one Cholesky each, hyperion/pdfs/plda/splda.py:112-142, becomes one
+ * pass):  T [m x ldt] holds gamma Q on entry and the posterior means y Q on return;
+ * logpy[i] (optional) = -K/2 log 2pi + 1/2 (log|L_i| - y_i . gamma_i)  (splda.py:106,142);
+ * *logpy_sum (optional) = sum_i logpy[i].  N are the m class counts (any positive reals). */
+int hypmi_splda_posterior(double* T, int64_t m, int64_t ldt, int K, const double* N, const double* lam,
+                          double* logpy, double* logpy_sum, void* stream);
+
 /* ---- x-vector loading (HOST functions: host pointers, no device, no stream) ------------------- */
 
 /* Shape of the record at byte `offset` of a Kaldi binary archive (the position an scp line names,

@@ -350,8 +350,76 @@ def gen_training_stats():
     print("training stats ok")
 
 
+def gen_splda_training():
+    """SPLDA EM training of the reference (hyperion/pdfs/plda/plda_base.py:34-88,
+    hyperion/pdfs/plda/splda.py:50-242) on labelled vectors: posterior of the first model, and the
+    ELBO sequence and final parameters of three training set-ups."""
+    rng = np.random.RandomState(77)
+    d, K, ncls = 8, 3, 40
+    counts = rng.randint(1, 7, ncls)
+    y = np.repeat(np.arange(ncls), counts)
+    n = y.shape[0]
+    Vt = rng.randn(K, d)
+    x = rng.randn(ncls, K)[y] @ Vt + 0.7 * rng.randn(n, d) * np.exp(rng.uniform(-0.5, 0.5, d)) + 1.5
+    perm = rng.permutation(n)
+    x, y = x[perm], y[perm]
+    w = rng.uniform(0.5, 2.0, n)
+    out = dict(x=x, y=y, w=w)
+
+    D = R.SPLDA.compute_stats_hard(x, y)
+    Dw = R.SPLDA.compute_stats_hard(x, y, sample_weight=w)
+    for tag, DD in (("", D), ("w_", Dw)):
+        r = R.SPLDA(y_dim=K)
+        r.initialize(DD)
+        out["init_" + tag + "mu"], out["init_" + tag + "V"], out["init_" + tag + "W"] = r.mu, r.V, r.W
+        mu, V, W = O.splda_initialize(DD, K)
+        close(mu, r.mu), close(V, r.V), close(W, r.W)
+        m0 = {"type": "splda", "mu": r.mu.copy(), "V": r.V.copy(), "W": r.W.copy()}
+        yy, cov, logpy, Ry, Py = r.compute_py_g_x(DD, return_cov=True, return_logpy_0=True, return_acc=True)
+        o = O.splda_compute_py_g_x(m0, DD, return_cov=True, return_logpy_0=True, return_acc=True)
+        for a, b in zip(o, (yy, cov, logpy, Ry, Py)):
+            close(a, b)
+        out["post_" + tag + "y"], out["post_" + tag + "cov"], out["post_" + tag + "logpy"] = yy, cov, logpy
+        out["post_" + tag + "Ry"], out["post_" + tag + "Py"] = Ry, Py
+        st = r.Estep(DD)
+        so = O.splda_estep(m0, DD)
+        for a, b in zip(so, st):
+            close(a, b)
+        out["elbo0_" + tag[:1]] = r.elbo(st)
+        close(O.splda_elbo(m0, so), r.elbo(st))
+
+    setups = {
+        "a": (D, dict(epochs=6, ml_md="ml+md"), {}),
+        "b": (Dw, dict(epochs=4, ml_md="ml"), {}),
+        "c": (D, dict(epochs=5, ml_md="ml+md", md_epochs=[1, 3]), dict(update_mu=False)),
+        "d": (D, dict(epochs=3, ml_md="md"), dict(update_W=False)),
+    }
+    for tag, (DD, kw, upd) in setups.items():
+        r = R.SPLDA(y_dim=K, **upd)
+        weights = w if DD is Dw else None
+        # fit() recomputes the statistics from x; sample weights are not passed on there
+        # (plda_base.py:56), so the weighted set-up drives the same loop on the weighted statistics
+        if weights is None:
+            elbo, elbo_norm = r.fit(x, class_ids=y, **kw)
+        else:
+            r.initialize(DD)
+            elbo = np.zeros(kw["epochs"])
+            for e in range(kw["epochs"]):
+                st = r.Estep(DD)
+                elbo[e] = r.elbo(st)
+                r.MstepML(st)
+            elbo_norm = elbo / np.sum(DD[0])
+        m, eo = O.splda_fit(DD, K, **kw, **upd)
+        close(eo, elbo, 1e-9), close(m["mu"], r.mu, 1e-8), close(m["V"], r.V, 1e-8), close(m["W"], r.W, 1e-8)
+        out["fit_%s_elbo" % tag], out["fit_%s_elbo_norm" % tag] = elbo, elbo_norm
+        out["fit_%s_mu" % tag], out["fit_%s_V" % tag], out["fit_%s_W" % tag] = r.mu, r.V, r.W
+    np.savez_compressed(os.path.join(OUT, "splda_training.npz"), **out)
+    print("splda training ok")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    gen_splda_training()
     gen_training_stats()
     gen_project()
     gen_selfcheck()

@@ -179,7 +179,7 @@ def llr_1vs1(model, x1, x2):
 def compute_stats_hard(x, class_ids):
     """hyperion/pdfs/plda/plda_base.py:249-274 without sample weights.  Classes are
     0..max(id); an id that never occurs gives N = 0 and F = 0 (later 0/0 = NaN, as in the
-    reference).  The second-order statistic is returned as None: no scoring path reads it."""
+    reference).  S = x^T x is the global second-order statistic that training reads."""
     num_classes = int(np.max(class_ids)) + 1
     N = np.zeros((num_classes,), dtype=F64)
     F = np.zeros((num_classes, x.shape[1]), dtype=F64)
@@ -187,7 +187,7 @@ def compute_stats_hard(x, class_ids):
         idx = class_ids == i
         N[i] = np.sum(idx)
         F[i] = np.sum(x[idx], axis=0)
-    return N, F, None
+    return N, F, np.dot(x.T, x)
 
 
 def _book_pair(F1, F2, n1, n2, proj_non, proj_tar, logL):
@@ -402,6 +402,146 @@ def sb_sw(x, class_ids):
         Sw += (xi - mi).T @ (xi - mi) / len(xi)
     mu /= len(u_ids)
     return mu, Sb / len(u_ids) - np.outer(mu, mu), Sw / len(u_ids)
+
+
+# ----------------------------------------------------------------------------- SPLDA training
+def _cho_solve_right(R, X):
+    """X @ inv(R.T R) as invert_pdmat(right_inv=True) does it (hyperion/utils/math.py:41)."""
+    return sla.cho_solve((R, False), X.T).T
+
+
+def splda_initialize(D, y_dim, fullcov_W=True):
+    """hyperion/pdfs/plda/splda.py:50-71: class means, their SVD for V, the residual scatter for W."""
+    N, F, S = D
+    Vytilde = F / N[:, None]
+    mu = np.mean(Vytilde, axis=0)
+    Vy = Vytilde - mu
+    _, s, Vt = sla.svd(Vy, full_matrices=False)
+    V = s[:y_dim, None] * Vt[:y_dim, :]
+    C = (S - np.dot((N[:, None] * Vytilde).T, Vytilde)) / np.sum(N)
+    W = inv_pdmat(C) if fullcov_W else 1 / np.diag(C)
+    return mu, V, W
+
+
+def splda_compute_py_g_x(m, D, return_cov=False, return_logpy_0=False, return_acc=False):
+    """hyperion/pdfs/plda/splda.py:73-158: posterior of the speaker factor of every class; the
+    classes are visited by distinct count when all counts are whole numbers, one by one otherwise."""
+    N, F, _ = D
+    mu, V, W = m["mu"], m["V"], m["W"]
+    y_dim = V.shape[0]
+    M = F.shape[0]
+    WV = np.dot(W, V.T)
+    VV = np.dot(V, WV)
+    gamma = np.dot(F - mu, WV)
+    whole = bool(np.all(np.ceil(N) == N))
+    compute_inv = return_cov or return_acc
+    y = np.zeros((M, y_dim))
+    Sigma_y = np.zeros((M, y_dim, y_dim)) if return_cov else None
+    logpy = -0.5 * y_dim * np.log(2 * np.pi) * np.ones((M,))
+    Py, Ry = np.zeros((y_dim, y_dim)), np.zeros((y_dim, y_dim))
+    for k in (np.unique(N) if whole else range(M)):
+        if whole:
+            i = (N == k).nonzero()[0]
+            N_i, M_i = k, len(i)
+        else:
+            i, N_i, M_i = k, N[k], 1
+        R = chol_upper(np.eye(y_dim) + N_i * VV)
+        y[i, :] = _cho_solve_right(R, gamma[i, :])
+        if compute_inv:
+            iL = _cho_solve_right(R, np.eye(y_dim))
+        if return_cov:
+            Sigma_y[i, :, :] = iL
+        if return_logpy_0:
+            logL = 2 * np.sum(np.log(np.diag(R)))
+            logpy[i] += 0.5 * (logL - np.sum(y[i, :] * gamma[i, :], axis=-1))
+        if return_acc:
+            Py += M_i * iL
+            Ry += N_i * M_i * iL
+    out = [y]
+    if return_cov:
+        out.append(Sigma_y)
+    if return_logpy_0:
+        out.append(logpy)
+    if return_acc:
+        out += [Ry, Py]
+    return out[0] if len(out) == 1 else tuple(out)
+
+
+def splda_estep(m, D):
+    """hyperion/pdfs/plda/splda.py:160-179."""
+    N, F, S = D
+    y, logpy, Ry, Py = splda_compute_py_g_x(m, D, return_logpy_0=True, return_acc=True)
+    Niy = y * N[:, None]
+    Ry = Ry + np.dot(Niy.T, y)
+    Py = Py + np.dot(y.T, y)
+    return (np.sum(N), F.shape[0], np.sum(F, axis=0), S, np.sum(logpy), np.sum(y, axis=0),
+            np.sum(Niy, axis=0), Ry, np.dot(F.T, y), Py)
+
+
+def splda_elbo(m, stats):
+    """hyperion/pdfs/plda/splda.py:181-196."""
+    N, M, F, S, logpy_x = stats[:5]
+    mu, V, W = m["mu"], m["V"], m["W"]
+    x_dim, y_dim = mu.shape[0], V.shape[0]
+    Fmu = np.outer(F, mu)
+    Shat = S - Fmu - Fmu.T + N * np.outer(mu, mu)
+    logpx_y = 0.5 * (-N * x_dim * np.log(2 * np.pi) + N * logdet_pdmat(W)
+                     - np.inner(W.ravel(), Shat.ravel()))
+    return logpx_y - 0.5 * M * y_dim * np.log(2 * np.pi) - logpy_x
+
+
+def splda_mstep_ml(m, stats, update_mu=True, update_V=True, update_W=True, fullcov_W=True):
+    """hyperion/pdfs/plda/splda.py:198-230; returns the updated model."""
+    N, M, F, S, _, y_acc, Ry1, Ry, Cy, Py = stats
+    mu, V, W = m["mu"], m["V"], m["W"]
+    Rytilde = np.vstack((np.hstack((Ry, Ry1[:, None])), np.hstack((Ry1, N))))
+    Cytilde = np.hstack((Cy, F[:, None]))
+    if update_mu and not update_V:
+        mu = (F - np.dot(Ry1, V)) / N
+    if not update_mu and update_V:
+        V = sla.cho_solve((chol_upper(Ry), False), Cy.T - np.outer(Ry1, mu))
+    if update_mu and update_V:
+        Vtilde = sla.cho_solve((chol_upper(Rytilde), False), Cytilde.T)
+        V, mu = Vtilde[:-1, :], Vtilde[-1, :]
+    if update_W:
+        if update_mu and update_V:
+            iW = (S - np.dot(Cy, V) - np.outer(F, mu)) / N
+        else:
+            Vtilde = np.vstack((V, mu))
+            CVt = np.dot(Cytilde, Vtilde)
+            iW = (S - CVt - CVt.T + np.dot(np.dot(Vtilde.T, Rytilde), Vtilde)) / N
+        W = inv_pdmat(iW) if fullcov_W else np.diag(1 / np.diag(iW))
+    return {"type": "splda", "mu": mu, "V": V, "W": W}
+
+
+def splda_mstep_md(m, stats, update_mu=True, update_V=True):
+    """hyperion/pdfs/plda/splda.py:232-242; returns the updated model."""
+    N, M, F, S, _, y_acc, Ry1, Ry, Cy, Py = stats
+    mu, V = m["mu"], m["V"]
+    mu_y = y_acc / M
+    if update_mu:
+        mu = mu + np.dot(mu_y, V)
+    if update_V:
+        V = np.dot(chol_upper(Py / M - np.outer(mu_y, mu_y)), V)
+    return {"type": "splda", "mu": mu, "V": V, "W": m["W"]}
+
+
+def splda_fit(D, y_dim, m=None, epochs=20, ml_md="ml+md", md_epochs=None, **updates):
+    """The training loop of hyperion/pdfs/plda/plda_base.py:34-88 on statistics D = (N, F, S):
+    returns (model, elbo per epoch)."""
+    if m is None:
+        mu, V, W = splda_initialize(D, y_dim, updates.get("fullcov_W", True))
+        m = {"type": "splda", "mu": mu, "V": V, "W": W}
+    elbo = np.zeros((epochs,))
+    md_kw = {k: v for k, v in updates.items() if k in ("update_mu", "update_V")}
+    for epoch in range(epochs):
+        stats = splda_estep(m, D)
+        elbo[epoch] = splda_elbo(m, stats)
+        if ml_md != "md":
+            m = splda_mstep_ml(m, stats, **updates)
+        if ml_md != "ml" and (md_epochs is None or epoch in md_epochs):
+            m = splda_mstep_md(m, stats, **md_kw)
+    return m, elbo
 
 
 def _largest_first_positive_top(V):

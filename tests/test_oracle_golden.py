@@ -168,3 +168,44 @@ def test_training_statistics_restatement(golden):
     for tag, kw in (("pca3_", dict(pca_dim=3)), ("pcar_", dict(pca_var_r=0.8, whiten=True))):
         mu, T = O.pca_fit(g["x"], **kw)
         assert T.shape == g[tag + "T"].shape and np.allclose(T, g[tag + "T"], rtol=1e-8, atol=1e-10)
+
+
+_SPLDA_SETUPS = {
+    "a": (False, dict(epochs=6, ml_md="ml+md"), {}),
+    "b": (True, dict(epochs=4, ml_md="ml"), {}),
+    "c": (False, dict(epochs=5, ml_md="ml+md", md_epochs=[1, 3]), dict(update_mu=False)),
+    "d": (False, dict(epochs=3, ml_md="md"), dict(update_W=False)),
+}
+
+
+def _weighted_stats(x, y, w):
+    ncls = int(y.max()) + 1
+    N = np.bincount(y, weights=w, minlength=ncls)
+    F = np.zeros((ncls, x.shape[1]))
+    np.add.at(F, y, x * w[:, None])
+    return N, F, (x * w[:, None]).T @ x
+
+
+def test_splda_training_restatement(golden):
+    """SPLDA EM of the oracle against the reference's first model, posterior, ELBO sequences and
+    trained parameters (fixture made by oracle/gen_golden.py gen_splda_training)."""
+    g = golden("splda_training")
+    x, y, w = g["x"], g["y"], g["w"]
+    K = g["init_V"].shape[0]
+    for tag, D in (("", O.compute_stats_hard(x, y)), ("w_", _weighted_stats(x, y, w))):
+        mu, V, W = O.splda_initialize(D, K)
+        assert np.allclose(mu, g["init_" + tag + "mu"], rtol=1e-10, atol=1e-12)
+        assert np.allclose(V, g["init_" + tag + "V"], rtol=1e-9, atol=1e-11)
+        assert np.allclose(W, g["init_" + tag + "W"], rtol=1e-9, atol=1e-11)
+        m0 = {"type": "splda", "mu": g["init_" + tag + "mu"], "V": g["init_" + tag + "V"],
+              "W": g["init_" + tag + "W"]}
+        got = O.splda_compute_py_g_x(m0, D, return_cov=True, return_logpy_0=True, return_acc=True)
+        for a, name in zip(got, ("y", "cov", "logpy", "Ry", "Py")):
+            assert np.allclose(a, g["post_" + tag + name], rtol=1e-9, atol=1e-11), name
+        assert np.isclose(O.splda_elbo(m0, O.splda_estep(m0, D)), g["elbo0_" + tag[:1]], rtol=1e-11)
+    for tag, (weighted, kw, upd) in _SPLDA_SETUPS.items():
+        D = _weighted_stats(x, y, w) if weighted else O.compute_stats_hard(x, y)
+        m, elbo = O.splda_fit(D, K, **kw, **upd)
+        assert np.allclose(elbo, g["fit_%s_elbo" % tag], rtol=1e-9)
+        for p in ("mu", "V", "W"):
+            assert np.allclose(m[p], g["fit_%s_%s" % (tag, p)], rtol=1e-7, atol=1e-9), (tag, p)
