@@ -106,11 +106,14 @@ class PLDABase(HypModel):
     def validate(self):
         raise NotImplementedError
 
+    def _validate_for_scoring(self):
+        self.validate()
+
     # ---- plans -----------------------------------------------------------------------------
     def score_plan(self, preproc=None, lnorm_first=False):
         """Device plan for [preproc chain ->] [LNorm() ->] this model's projection.  `preproc` is
         a hyperion_amd TransformList (or a list of transforms) folded in front of the model."""
-        self.validate()
+        self._validate_for_scoring()
         transforms = []
         if preproc is not None:
             transforms = list(getattr(preproc, "transforms", preproc))

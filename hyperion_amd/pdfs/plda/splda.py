@@ -29,6 +29,14 @@ class SPLDA(PLDABase):
         assert self.mu.shape[0] == self.W.shape[1]
         self.x_dim = self.mu.shape[0]
 
+    def _validate_for_scoring(self):
+        """Shapes only: a model projected onto fewer dimensions than y_dim (project() after a PCA on
+        a short recording) scores in the reference, whose llr_1vs1 never validates."""
+        assert self.mu is not None and self.V is not None and self.W is not None
+        d = self.mu.shape[0]
+        assert self.V.shape[1] == d and self.W.shape[0] == d and self.W.shape[-1] == d
+        self.x_dim = d
+
     @property
     def is_init(self):
         if not self._is_init and self.mu is not None and self.V is not None and self.W is not None:

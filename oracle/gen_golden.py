@@ -417,8 +417,35 @@ def gen_splda_training():
     print("splda training ok")
 
 
+def gen_diarization():
+    """The diarization consumer of the reference (hyperion/diarization/diar_ahc_plda.py:122-168,
+    hyperion/clustering/ahc.py:36-110): length normalisation, PCA fitted on the recording, projected
+    SPLDA model, self-scoring, average-linkage AHC cut at a threshold."""
+    from hyperion.diarization.diar_ahc_plda import DiarAHCPLDA
+
+    rng = np.random.RandomState(21)
+    m = small_models(12, 4, 9)["splda"]
+    model = ref_model(m)
+    spk = rng.randint(0, 3, 90)
+    y = 2.0 * rng.randn(3, 4)[spk]
+    x = m["mu"] + y @ m["V"] + rng.multivariate_normal(np.zeros(12), np.linalg.inv(m["W"]), 90)
+    out = dict(x=x, spk=spk)
+    out.update(flat("m_", m))
+    for tag, var_r, thr in (("full", 1, 4.0), ("pca", 0.8, 2.0)):
+        diar = DiarAHCPLDA(ref_model(m), preproc=R.LNorm(), threshold=thr, pca_var_r=var_r)
+        ids = diar.cluster(x.copy())
+        out["ids_" + tag], out["Z_" + tag] = ids, diar._ahc.Z
+        got = O.diar_ahc_plda_cluster(m, x, thr, var_r)
+        assert np.array_equal(got[0], ids)
+        close(got[1], diar._ahc.Z, 1e-9)
+        print("diarization", tag, "clusters:", len(np.unique(ids)))
+    np.savez_compressed(os.path.join(OUT, "diarization.npz"), **out)
+    print("diarization ok")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    gen_diarization()
     gen_splda_training()
     gen_training_stats()
     gen_project()

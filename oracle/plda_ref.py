@@ -127,6 +127,38 @@ def splda_project(mu, V, W, T, delta_mu=None):
     return mu @ T, V @ T, inv_pdmat(Sw)
 
 
+def splda_torch_layer_llr(x1, x2, mu, V, U, lnorm=False):
+    """The scoring formula of the reference's trainable SPLDA layer
+    (hyperion/torch/models/plda/splda.py:112-222, in numpy): the within-class precision is
+    parametrised as W = U U^T, the optional `lnorm` is sqrt(d) x / |x| (torch/models/plda/
+    plda_base.py:85-86), the triangular factors are applied from the right, and the scores are
+    0.5 (2 Qtar_12 + (Qtar_1 - Qnon_1) + (Qtar_2 - Qnon_2) + 2 logLnon - logLtar).  x2 = None gives
+    `llr_self`.  (The layer itself cannot be built under this image's torch: its constructor calls
+    torch.symeig, splda.py:72, which torch 2 removed.)"""
+    if x2 is None:
+        x2 = x1
+    if lnorm:
+        x1 = np.sqrt(x1.shape[-1]) * x1 / np.linalg.norm(x1, axis=-1, keepdims=True)
+        x2 = np.sqrt(x2.shape[-1]) * x2 / np.linalg.norm(x2, axis=-1, keepdims=True)
+    W = np.dot(U, U.T)
+    WV = np.dot(W, V.T)
+    VV = np.dot(V, WV)
+    I = np.eye(V.shape[0])
+    Rnon, Rtar = chol_upper(I + VV), chol_upper(I + 2 * VV)
+    logLnon = 2 * np.sum(np.log(np.diag(Rnon)))
+    logLtar = 2 * np.sum(np.log(np.diag(Rtar)))
+    VWF1, VWF2 = np.dot(x1 - mu, WV), np.dot(x2 - mu, WV)
+    gn1, gn2 = right_solve_upper(Rnon, VWF1), right_solve_upper(Rnon, VWF2)
+    gt1, gt2 = right_solve_upper(Rtar, VWF1), right_solve_upper(Rtar, VWF2)
+    Q1 = (np.sum(gt1 * gt1, axis=1) - np.sum(gn1 * gn1, axis=1))[:, None]
+    Q2 = np.sum(gt2 * gt2, axis=1) - np.sum(gn2 * gn2, axis=1)
+    scores = 2 * np.dot(gt1, gt2.T)
+    scores += Q1 + Q2
+    scores += logLnon + logLnon - logLtar
+    scores *= 0.5
+    return scores
+
+
 def plda_aux(V, U, D):
     """hyperion/pdfs/plda/plda.py:77-89: returns (_VW [d, y_dim], _VWV [y_dim, y_dim])."""
     DV = V * D
@@ -402,6 +434,49 @@ def sb_sw(x, class_ids):
         Sw += (xi - mi).T @ (xi - mi) / len(xi)
     mu /= len(u_ids)
     return mu, Sb / len(u_ids) - np.outer(mu, mu), Sw / len(u_ids)
+
+
+# ----------------------------------------------------------------------------- diarization consumer
+def ahc_fit(scores, method="average"):
+    """hyperion/clustering/ahc.py:36-59, metric "llr": linkage on max - score over the upper
+    triangle, heights mapped back to scores."""
+    from scipy.cluster.hierarchy import linkage
+
+    idx = np.triu(np.ones_like(scores, dtype=bool), k=1)
+    s = scores[idx]
+    max_score = np.max(s)
+    Z = linkage(-s + max_score, method=method)
+    Z[:, 2] = -Z[:, 2] + max_score
+    return Z
+
+
+def ahc_flat_clusters(Z, thr):
+    """hyperion/clustering/ahc.py:81-110: merges whose score is >= thr are applied in order; labels
+    are the ranks of the surviving node numbers."""
+    return ahc_flat_clusters_n(Z, Z.shape[0] + 1 - int(np.sum(Z[:, 2] >= thr)))
+
+
+def ahc_flat_clusters_n(Z, num_clusters):
+    """hyperion/clustering/ahc.py:81-99: the first N - num_clusters merges applied in order."""
+    N = Z.shape[0] + 1
+    num_clusters = min(N, num_clusters)
+    flat = np.arange(N, dtype=int)
+    for i in range(N - num_clusters):
+        flat[np.logical_or(flat == Z[i, 0], flat == Z[i, 1])] = N + i
+    return np.unique(flat, return_inverse=True)[1]
+
+
+def diar_ahc_plda_cluster(m, x, threshold=0.0, pca_var_r=1):
+    """hyperion/diarization/diar_ahc_plda.py:122-168 with a parameter-free LNorm as the
+    pre-processor and without the optional score calibration: (cluster ids, linkage)."""
+    x = lnorm_predict(x)
+    mu, V, W = m["mu"], m["V"], m["W"]
+    if pca_var_r < 1:
+        pmu, T = pca_fit(x, pca_var_r=pca_var_r, whiten=True)
+        x = lnorm_predict(np.dot(x - pmu, T))
+        mu, V, W = splda_project(mu, V, W, T, pmu)
+    Z = ahc_fit(splda_llr_1vs1(x, x, mu, V, W))
+    return ahc_flat_clusters(Z, threshold), Z
 
 
 # ----------------------------------------------------------------------------- SPLDA training

@@ -679,3 +679,25 @@ def test_projected_model_self_scoring(golden):
     err = np.abs(s - g["scores"]) / np.maximum(np.abs(g["scores"]), 1.0)
     assert err.max() <= 1e-4, err.max()
     assert np.max(np.abs(s - s.T)) <= 1e-4 * np.abs(s).max()
+
+
+def test_scores_agree_with_the_trainable_layer_formula(golden):
+    """Independent statement of the closed form (the reference's trainable SPLDA layer, W = U U^T,
+    optional length normalisation inside the model: hyperion/torch/models/plda/splda.py:182-222)
+    against the device scores, cross and self."""
+    from hyperion_amd.pdfs.plda import SPLDA
+
+    g = golden("llr_1vs1")
+    m = model_from(g, "splda_b_", "splda")
+    x1, x2 = g["x1_b"], g["x2_b"]
+    ev, E = np.linalg.eigh(m["W"])
+    U = E * np.sqrt(ev)
+    model = SPLDA(mu=m["mu"], V=m["V"], W=m["W"])
+    for a, b in ((x1, x2), (x1, None)):
+        ref = O.splda_torch_layer_llr(a, b, m["mu"], m["V"], U)
+        got = model.llr_1vs1(a, a if b is None else b)
+        assert np.allclose(got, ref, rtol=1e-4, atol=0)
+        ref = O.splda_torch_layer_llr(a, b, m["mu"], m["V"], U, lnorm=True)
+        bb = a if b is None else b
+        got = model.llr_NvsM(a, bb, ids1=np.arange(len(a)), ids2=np.arange(len(bb)), method="vavg-lnorm")
+        assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)) <= 1e-4

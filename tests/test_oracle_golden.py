@@ -209,3 +209,20 @@ def test_splda_training_restatement(golden):
         assert np.allclose(elbo, g["fit_%s_elbo" % tag], rtol=1e-9)
         for p in ("mu", "V", "W"):
             assert np.allclose(m[p], g["fit_%s_%s" % (tag, p)], rtol=1e-7, atol=1e-9), (tag, p)
+
+
+def test_torch_layer_formula_agrees_with_numpy_model(golden):
+    """The trainable SPLDA layer of the reference states the same score with W = U U^T
+    (hyperion/torch/models/plda/splda.py:182-222): an independent statement of the closed form, checked
+    against the reference's numpy scores of the 1-vs-1 fixture."""
+    g = golden("llr_1vs1")
+    for case in ("a", "b"):
+        m = model_from(g, "splda_%s_" % case, "splda")
+        x1, x2 = g["x1_" + case], g["x2_" + case]
+        ev, E = np.linalg.eigh(m["W"])
+        U = E * np.sqrt(ev)
+        s = O.splda_torch_layer_llr(x1, x2, m["mu"], m["V"], U)
+        assert np.allclose(s, g["splda_%s_scores" % case], rtol=1e-9, atol=1e-9)
+        self_scores = O.splda_torch_layer_llr(x1, None, m["mu"], m["V"], U)
+        assert np.allclose(self_scores, O.llr_1vs1(m, x1, x1), rtol=1e-9, atol=1e-9)
+        assert np.allclose(self_scores, self_scores.T, rtol=1e-12, atol=1e-12)
