@@ -54,6 +54,10 @@ class PlanDesc(ctypes.Structure):
         ("bn", c_double_p),
         ("K", i32),
         ("c", ctypes.c_double),
+        ("shift_t", c_double_p),
+        ("scale_t", c_double_p),
+        ("shift_n", c_double_p),
+        ("scale_n", c_double_p),
     ]
 
 

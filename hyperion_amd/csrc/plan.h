@@ -48,7 +48,12 @@ struct FusedTail {
 struct hypmi_plan {
     int d_in = 0, n_seg = 0, d_last = 0, K = 0, KP = 0;
     Segment seg[HYPMI_MAX_SEG];
-    Segment fin;  // [At | An]^T, 2K outputs
+    Segment fin;  // [At | An]^T, 2K outputs (shared-basis plans: the float64 path only)
+    // shared-basis form: one K-column projection s, then g_k = (s_k + shift_t[k]) scale_t[k] and
+    // h_k = (s_k + shift_n[k]) scale_n[k]
+    bool shared = false;
+    Segment sfin;  // K outputs
+    float* col_map = nullptr;  // shift_t | scale_t | shift_n | scale_n, K floats each
     FusedTail fused;
     double c = 0.0;
     int max_dim = 0;

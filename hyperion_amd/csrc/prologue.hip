@@ -78,6 +78,8 @@ extern "C" void hypmi_plan_destroy(hypmi_plan* p) {
         p->seg[i].release();
     }
     p->fin.release();
+    p->sfin.release();
+    if (p->col_map) (void)hipFree(p->col_map);
     p->fused.release();
     delete p;
 }
@@ -87,7 +89,10 @@ extern "C" int hypmi_plan_create(const hypmi_plan_desc* d, hypmi_plan** out) {
     HYPMI_REQUIRE(d->d_in > 0, "plan_create: d_in must be positive");
     HYPMI_REQUIRE(d->n_seg >= 0 && d->n_seg <= HYPMI_MAX_SEG, "plan_create: n_seg out of range");
     HYPMI_REQUIRE(d->K >= 0, "plan_create: negative K");
-    HYPMI_REQUIRE(d->K == 0 || (d->At && d->An), "plan_create: At/An required when K > 0");
+    const bool shared = d->K > 0 && d->scale_t != nullptr;
+    HYPMI_REQUIRE(d->K == 0 || (d->At && (d->An || shared)), "plan_create: At/An required when K > 0");
+    HYPMI_REQUIRE(!shared || (d->shift_t && d->shift_n && d->scale_n),
+                  "plan_create: the shared-basis form needs shift_t, scale_t, shift_n and scale_n");
     hypmi_plan* p = new hypmi_plan();
     p->d_in = d->d_in;
     p->n_seg = d->n_seg;
@@ -124,25 +129,59 @@ extern "C" int hypmi_plan_create(const hypmi_plan_desc* d, hypmi_plan** out) {
     if (rc == HYPMI_OK && d->K > 0) {
         const int K = d->K;
         std::vector<double> W((size_t)cur * 2 * K), b(2 * K, 0.0);
-        for (int i = 0; i < cur; ++i)
+        if (shared) {
+            // the two-projection form of the same model, for the float64 path
+            for (int i = 0; i < cur; ++i)
+                for (int j = 0; j < K; ++j) {
+                    W[(size_t)i * 2 * K + j] = d->At[(size_t)i * K + j] * d->scale_t[j];
+                    W[(size_t)i * 2 * K + K + j] = d->At[(size_t)i * K + j] * d->scale_n[j];
+                }
             for (int j = 0; j < K; ++j) {
-                W[(size_t)i * 2 * K + j] = d->At[(size_t)i * K + j];
-                W[(size_t)i * 2 * K + K + j] = d->An[(size_t)i * K + j];
+                const double bj = d->bt ? d->bt[j] : 0.0;
+                b[j] = (bj + d->shift_t[j]) * d->scale_t[j];
+                b[K + j] = (bj + d->shift_n[j]) * d->scale_n[j];
             }
-        for (int j = 0; j < K; ++j) {
-            if (d->bt) b[j] = d->bt[j];
-            if (d->bn) b[K + j] = d->bn[j];
+        } else {
+            for (int i = 0; i < cur; ++i)
+                for (int j = 0; j < K; ++j) {
+                    W[(size_t)i * 2 * K + j] = d->At[(size_t)i * K + j];
+                    W[(size_t)i * 2 * K + K + j] = d->An[(size_t)i * K + j];
+                }
+            for (int j = 0; j < K; ++j) {
+                if (d->bt) b[j] = d->bt[j];
+                if (d->bn) b[K + j] = d->bn[j];
+            }
         }
         p->fin.d_in = cur;
         p->fin.d_out = 2 * K;
         rc = upload_transposed(W.data(), cur, 2 * K, &p->fin);
         if (rc == HYPMI_OK) rc = upload_vec(b.data(), 2 * K, &p->fin);
         p->KP = hypmi_kp_for_k(K);
+        if (rc == HYPMI_OK && shared) {
+            p->shared = true;
+            p->sfin.d_in = cur;
+            p->sfin.d_out = K;
+            std::vector<double> sb(K, 0.0);
+            if (d->bt) sb.assign(d->bt, d->bt + K);
+            rc = upload_transposed(d->At, cur, K, &p->sfin);
+            if (rc == HYPMI_OK) rc = upload_vec(sb.data(), K, &p->sfin);
+            std::vector<float> cm((size_t)4 * K);
+            for (int j = 0; j < K; ++j) {
+                cm[j] = (float)d->shift_t[j];
+                cm[K + j] = (float)d->scale_t[j];
+                cm[2 * K + j] = (float)d->shift_n[j];
+                cm[3 * K + j] = (float)d->scale_n[j];
+            }
+            if (rc == HYPMI_OK) rc = to_device(cm, &p->col_map);
+            // from here on W / NV describe the projection the fp32 path applies
+            W.assign(d->At, d->At + (size_t)cur * K);
+        }
+        const int NVp = shared ? K : 2 * K;
         // fold the last length-normalised segment into the projection
         if (rc == HYPMI_OK && d->n_seg > 0 && d->seg[d->n_seg - 1].lnorm) {
             const hypmi_segment& ls = d->seg[d->n_seg - 1];
             const int dp = p->seg[d->n_seg - 1].d_in;  // input dim of that segment
-            const int D1 = cur, NV = 2 * K;
+            const int D1 = cur, NV = NVp;
             FusedTail& f = p->fused;
             f.d_in = dp;
             f.n_u = ls.A ? D1 : 0;
@@ -392,13 +431,14 @@ __global__ __launch_bounds__(256) void prologue_fused_kernel(
 int run_fused_tail(const hypmi_plan* p, const float* in, int64_t ldin, int64_t rows, float* Z, int64_t ldz,
                    hipStream_t stream) {
     const FusedTail& f = p->fused;
+    const float* bias_out = p->shared ? p->sfin.bias : p->fin.bias;
     if (rows >= 128 * 2048) {
         hipLaunchKernelGGL(prologue_fused_kernel<2>, dim3((unsigned)((rows + 127) / 128)), dim3(256), 0, stream,
-                           in, ldin, rows, f.d_in, f.Wcat, f.ldw, f.bias_u, f.bias_vin, p->fin.bias, f.n_u,
+                           in, ldin, rows, f.d_in, f.Wcat, f.ldw, f.bias_u, f.bias_vin, bias_out, f.n_u,
                            f.n_v, f.sqrt_dn, f.norm_from_input ? 1 : 0, Z, ldz);
     } else {
         hipLaunchKernelGGL(prologue_fused_kernel<1>, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, stream, in,
-                           ldin, rows, f.d_in, f.Wcat, f.ldw, f.bias_u, f.bias_vin, p->fin.bias, f.n_u, f.n_v,
+                           ldin, rows, f.d_in, f.Wcat, f.ldw, f.bias_u, f.bias_vin, bias_out, f.n_u, f.n_v,
                            f.sqrt_dn, f.norm_from_input ? 1 : 0, Z, ldz);
     }
     HYPMI_HIP(hipGetLastError());
@@ -516,15 +556,23 @@ extern "C" int hypmi_prologue(const hypmi_plan* p, const float* x, int64_t n, in
         rc = run_segments(p, fuse ? p->n_seg - 1 : p->n_seg, x + r0 * ldx, ldx, rows, w, nullptr, 0, &cur,
                           &ldcur, stream);
         if (rc != HYPMI_OK) return rc;
+        const Segment& fin = p->shared ? p->sfin : p->fin;
         if (fuse)
             rc = run_fused_tail(p, cur, ldcur, rows, w.z, w.ldz, stream);
         else
-            rc = hypmi_launch_gemm_nt(cur, ldcur, p->fin.Wt, p->fin.ldw, p->fin.bias, w.z, w.ldz, rows,
-                                      2 * p->K, p->fin.d_in, stream);
+            rc = hypmi_launch_gemm_nt(cur, ldcur, fin.Wt, fin.ldw, fin.bias, w.z, w.ldz, rows, fin.d_out,
+                                      fin.d_in, stream);
         if (rc != HYPMI_OK) return rc;
-        hipLaunchKernelGGL(pack_gq_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, w.z,
-                           rows, w.ldz, p->K, p->KP, side, p->c, G + r0 * p->KP);
-        HYPMI_HIP(hipGetLastError());
+        if (p->shared) {
+            const float* cm = p->col_map;
+            rc = hypmi_book_pack(w.z, w.ldz, p->K, nullptr, rows, cm, cm + p->K, cm + 2 * p->K, cm + 3 * p->K,
+                                 side, p->c, G + r0 * p->KP, p->KP, stream);
+            if (rc != HYPMI_OK) return rc;
+        } else {
+            hipLaunchKernelGGL(pack_gq_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, w.z,
+                               rows, w.ldz, p->K, p->KP, side, p->c, G + r0 * p->KP);
+            HYPMI_HIP(hipGetLastError());
+        }
     }
     return HYPMI_OK;
 }

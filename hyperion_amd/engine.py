@@ -195,9 +195,12 @@ class Plan:
     """Device-resident folded model (hypmi_plan).  `segments` is a list of (A, b, d_out) affine
     maps each followed by a length normalisation; `tail` = (A, b) is applied after the last
     normalisation; `proj` = (At, bt, An, bn, c) is the PLDA projection (None for a
-    transform-only plan, in which case the tail becomes a final un-normalised segment)."""
+    transform-only plan, in which case the tail becomes a final un-normalised segment).
+    `shared` = dict(P, pb, shift_t, scale_t, shift_n, scale_n) is the same projection in the basis
+    where g and h are per-column maps of one K-column projection s = y P + pb (see
+    hypmi_plan_desc): the device then projects onto K columns instead of 2K."""
 
-    def __init__(self, d_in, segments=(), tail=(None, None), proj=None):
+    def __init__(self, d_in, segments=(), tail=(None, None), proj=None, shared=None):
         require_gpu()
         lib = _lib.load()
         from .fold import compose
@@ -215,15 +218,23 @@ class Plan:
             desc.K = 0
         else:
             At, bt, An, bn, c = proj
-            (At2, bt2) = compose(tail, (At, bt))
-            (An2, bn2) = compose(tail, (An, bn))
+            if shared is not None:
+                (At2, bt2) = compose(tail, (shared["P"], shared["pb"]))
+                for name in ("shift_t", "scale_t", "shift_n", "scale_n"):
+                    a, ptr = _as_c(shared[name])
+                    assert a.shape == (At2.shape[1],)
+                    setattr(desc, name, ptr)
+                    keep.append(a)
+            else:
+                (At2, bt2) = compose(tail, (At, bt))
+                (An2, bn2) = compose(tail, (An, bn))
+                a, desc.An = _as_c(An2)
+                keep.append(a)
+                a, desc.bn = _as_c(bn2)
+                keep.append(a)
             a, desc.At = _as_c(At2)
             keep.append(a)
             a, desc.bt = _as_c(bt2)
-            keep.append(a)
-            a, desc.An = _as_c(An2)
-            keep.append(a)
-            a, desc.bn = _as_c(bn2)
             keep.append(a)
             desc.K = int(At2.shape[1])
             desc.c = float(c)

@@ -106,6 +106,20 @@ class PLDABase(HypModel):
     def validate(self):
         raise NotImplementedError
 
+    def _shared_fold(self):
+        """The 1-vs-1 projection in the basis of by-the-book scoring, one segment a side: both
+        gamma_tar and gamma_non are per-column maps of s = x P + row_bias there
+        (|gamma(n)|^2 = sum_k (s_k + shift_k)^2 / (1 + n lam_k)), so the device needs K columns, not
+        2K.  The constant must be the one of _fold()."""
+        bf = self._book_fold()
+        lam = bf["lam"]
+        c = 0.5 * (2.0 * float(np.sum(np.log1p(lam))) - float(np.sum(np.log1p(2.0 * lam)))) + bf["c_extra"]
+        c_ref = float(self._fold()[4])
+        if abs(c - c_ref) > 1e-8 * max(1.0, abs(c_ref)):
+            raise AssertionError("shared-basis constant %r differs from %r" % (c, c_ref))
+        return {"P": bf["P"], "pb": bf["row_bias"], "shift_t": bf["shift_t"], "shift_n": bf["shift_n"],
+                "scale_t": 1.0 / np.sqrt(1.0 + 2.0 * lam), "scale_n": 1.0 / np.sqrt(1.0 + lam)}
+
     def _validate_for_scoring(self):
         self.validate()
 
@@ -138,7 +152,7 @@ class PLDABase(HypModel):
                                  % (d_out, self.x_dim))
             if len(self._plans) > 8:
                 self._plans.clear()
-            plan = engine.Plan(d_in, segments, tail, self._fold())
+            plan = engine.Plan(d_in, segments, tail, self._fold(), shared=self._shared_fold())
             self._plans[key] = plan
         return plan
 

@@ -57,7 +57,15 @@ typedef struct {
  *   h = y An + bn   (gamma_non, splda.py:300-301)
  * and the additive constant c (splda.py:314-315: (2 logLnon - logLtar)/2).  At/An are
  * [d_last x K] row-major fp64 host arrays, bt/bn [K] (NULL = 0).  The host computes them in fp64
- * (Cholesky and triangular solves act on K x K matrices only). */
+ * (Cholesky and triangular solves act on K x K matrices only).
+ *
+ * Shared-basis form (scale_t != NULL): in the basis that diagonalises the model's L matrices
+ * (I + n V W V^T, or B + n W) the two projections are one projection s = y At + bt followed by a
+ * map per column,
+ *   g_k = (s_k + shift_t[k]) scale_t[k],   h_k = (s_k + shift_n[k]) scale_n[k]
+ * (the by-the-book scoring of splda.py:334-375 for one segment a side), so the device projects onto
+ * K columns instead of 2K.  An/bn are then ignored and may be NULL; the four vectors are [K] fp64
+ * host arrays.  The scores are those of the two-projection form: g differs by a rotation. */
 typedef struct {
     int32_t d_in;
     int32_t n_seg;
@@ -68,6 +76,10 @@ typedef struct {
     const double* bn;
     int32_t K;
     double c;
+    const double* shift_t;
+    const double* scale_t;
+    const double* shift_n;
+    const double* scale_n;
 } hypmi_plan_desc;
 
 const char* hypmi_last_error(void);

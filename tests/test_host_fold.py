@@ -141,3 +141,28 @@ def test_savg_is_bilinear(golden, kind):
     G2 = mean_by(packed(g["x2"], True), g["ids2"])
     ref = g["%s_NvsM_savg" % kind]
     assert np.max(np.abs(G1 @ G2.T - ref)) <= 1e-10 * max(1.0, np.max(np.abs(ref)))
+
+
+@pytest.mark.parametrize("kind", ["splda", "frplda", "plda"])
+def test_shared_basis_projection_gives_the_same_scores(golden, kind):
+    """The K-column form the device projects with: g and h as per-column maps of one projection."""
+    from hyperion_amd.pdfs.plda import FRPLDA, PLDA, SPLDA
+
+    g = golden("llr_1vs1")
+    for tag in "ab":
+        m = model_from(g, "%s_%s_" % (kind, tag), kind)
+        model = {"splda": SPLDA, "frplda": FRPLDA, "plda": PLDA}[kind](**{k: v for k, v in m.items() if k != "type"})
+        sh = model._shared_fold()
+        c = model._fold()[4]
+
+        def rows(x):
+            s = x @ sh["P"] + sh["pb"]
+            gg = (s + sh["shift_t"]) * sh["scale_t"]
+            hh = (s + sh["shift_n"]) * sh["scale_n"]
+            return gg, 0.5 * (np.sum(gg * gg, 1) - np.sum(hh * hh, 1))
+
+        (g1, q1), (g2, q2) = rows(g["x1_" + tag]), rows(g["x2_" + tag])
+        s = g1 @ g2.T + q1[:, None] + q2[None, :] + c
+        ref = g["%s_%s_scores" % (kind, tag)]
+        assert sh["P"].shape[1] == model._fold()[0].shape[1]
+        assert np.max(np.abs(s - ref)) <= 1e-10 * max(1.0, np.max(np.abs(ref)))
