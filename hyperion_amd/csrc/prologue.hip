@@ -327,6 +327,35 @@ __global__ __launch_bounds__(256) void pack_gq_kernel(const float* __restrict__ 
     }
 }
 
+// One column chunk (64 TN columns) of the projection walk of prologue_fused_kernel:
+// z = sc * (x Wv^T + bias_in) + bias_out for the workgroup's rows.
+template <int TM, int TN>
+__device__ __forceinline__ void fused_v_chunk(const float* __restrict__ x, int64_t ldx,
+                                              const float* __restrict__ Wv, int64_t ldw, int64_t m0, int n0,
+                                              int64_t n, int n_v, int d_in, float* smem,
+                                              const float (&sc)[TM][16], const float* __restrict__ bias_vin,
+                                              const float* __restrict__ bias_vout, float* __restrict__ Z,
+                                              int64_t ldz) {
+    f32x16 acc[TM][TN];
+    gemm_tile::zero<TM, TN>(acc);
+    gemm_tile::mainloop<TM, TN>(x, ldx, Wv, ldw, m0, n0, n, n_v, d_in, smem, acc);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + gemm_tile::col_of<TN>(j);
+        if (col < n_v) {
+            const float bi = bias_vin ? bias_vin[col] : 0.f;
+            const float bo = bias_vout ? bias_vout[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t row = m0 + gemm_tile::row_of<TM>(i, e);
+                    if (row < n) Z[row * ldz + col] = fmaf(sc[i][e], acc[i][j][e] + bi, bo);
+                }
+        }
+    }
+}
+
 // Fused tail of the prologue: affine + length norm + PLDA projection in one pass over the rows.
 // A workgroup owns 64*TM rows.  It first walks the n_u columns of u = x A1 + b1 in 128-column
 // chunks, keeping only per-row sums of squares (u never leaves the chip), turns them into the
@@ -407,25 +436,12 @@ __global__ __launch_bounds__(256) void prologue_fused_kernel(
             sc[i][e] = sqrt_dn / (sqrtf(rowsq[0][rr] + rowsq[1][rr]) + 1e-10f);
         }
     const float* Wv = Wcat + (int64_t)n_u * ldw;
-    for (int n0 = 0; n0 < n_v; n0 += 128) {
-        gemm_tile::zero<TM, 2>(acc);
-        gemm_tile::mainloop<TM, 2>(x, ldx, Wv, ldw, m0, n0, n, n_v, d_in, smem, acc);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + gemm_tile::col_of<2>(j);
-            if (col < n_v) {
-                const float bi = bias_vin ? bias_vin[col] : 0.f;
-                const float bo = bias_vout ? bias_vout[col] : 0.f;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int64_t row = m0 + gemm_tile::row_of<TM>(i, e);
-                        if (row < n) Z[row * ldz + col] = fmaf(sc[i][e], acc[i][j][e] + bi, bo);
-                    }
-            }
-        }
-    }
+    // 128-column chunks; a remainder of at most 64 columns runs as a 64-column chunk
+    int n0 = 0;
+    for (; n_v - n0 > 64; n0 += 128)
+        fused_v_chunk<TM, 2>(x, ldx, Wv, ldw, m0, n0, n, n_v, d_in, smem, sc, bias_vin, bias_vout, Z, ldz);
+    if (n0 < n_v)
+        fused_v_chunk<TM, 1>(x, ldx, Wv, ldw, m0, n0, n, n_v, d_in, smem, sc, bias_vin, bias_vout, Z, ldz);
 }
 
 int run_fused_tail(const hypmi_plan* p, const float* in, int64_t ldin, int64_t rows, float* Z, int64_t ldz,
