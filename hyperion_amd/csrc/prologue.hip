@@ -399,18 +399,20 @@ __global__ __launch_bounds__(256) void prologue_fused_kernel(
         }
     }
     if (norm_from_input) {
-        // identity matrix: |u| is the norm of the input row itself (plus the bias, if any)
-        for (int rr = wave; rr < BM; rr += 4) {
+        // identity matrix: |u| is the norm of the input row itself (plus the bias, if any).
+        // Sixteen lanes per row, four rows per wave at a time: the rows' loads are independent.
+        const int sub = lane >> 4, l16 = lane & 15;
+        for (int rr = 4 * wave + sub; rr < BM; rr += 16) {
             const int64_t row = m0 + rr;
             float a2 = 0.f;
             if (row < n)
-                for (int kk = lane; kk < d_in; kk += 64) {
+                for (int kk = l16; kk < d_in; kk += 16) {
                     const float v = x[row * ldx + kk] + (bias_u ? bias_u[kk] : 0.f);
                     a2 = fmaf(v, v, a2);
                 }
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) a2 += __shfl_xor(a2, off, 64);
-            if (lane == 0) {
+            for (int off = 8; off > 0; off >>= 1) a2 += __shfl_xor(a2, off, 64);
+            if (l16 == 0) {
                 rowsq[0][rr] = a2;
                 rowsq[1][rr] = 0.f;
             }

@@ -90,6 +90,7 @@ class PLDABase(HypModel):
         if mu is not None:
             self.x_dim = mu.shape[0]
         self._plans = {}
+        self._book_cache = (None, None)
 
     # ---- to be provided by the concrete model ---------------------------------------------
     def _params(self):
@@ -106,12 +107,21 @@ class PLDABase(HypModel):
     def validate(self):
         raise NotImplementedError
 
+    @engine.small_host_algebra
+    def _book_fold_cached(self):
+        """_book_fold() of the current parameters (an eigendecomposition; kept until they change)."""
+        key = fingerprint(*self._params())
+        if self._book_cache[0] != key:
+            self._book_cache = (key, self._book_fold())
+        return self._book_cache[1]
+
+    @engine.small_host_algebra
     def _shared_fold(self):
         """The 1-vs-1 projection in the basis of by-the-book scoring, one segment a side: both
         gamma_tar and gamma_non are per-column maps of s = x P + row_bias there
         (|gamma(n)|^2 = sum_k (s_k + shift_k)^2 / (1 + n lam_k)), so the device needs K columns, not
         2K.  The constant must be the one of _fold()."""
-        bf = self._book_fold()
+        bf = self._book_fold_cached()
         lam = bf["lam"]
         c = 0.5 * (2.0 * float(np.sum(np.log1p(lam))) - float(np.sum(np.log1p(2.0 * lam)))) + bf["c_extra"]
         c_ref = float(self._fold()[4])
@@ -124,6 +134,7 @@ class PLDABase(HypModel):
         self.validate()
 
     # ---- plans -----------------------------------------------------------------------------
+    @engine.small_host_algebra
     def score_plan(self, preproc=None, lnorm_first=False):
         """Device plan for [preproc chain ->] [LNorm() ->] this model's projection.  `preproc` is
         a hyperion_amd TransformList (or a list of transforms) folded in front of the model."""
@@ -302,6 +313,19 @@ class PLDABase(HypModel):
             return S
         return engine.to_host(S, float_cpu())
 
+    @staticmethod
+    def _book_result(S, *sides):
+        """The caller gets a device matrix only for device inputs (vectors, or the F of a statistics
+        tuple when ids is None); the statistics built here from host vectors do not count."""
+        torch = engine.require_gpu()
+        if not isinstance(S, torch.Tensor):
+            return S
+        for x, ids in sides:
+            given = x[1] if ids is None else x
+            if not isinstance(given, torch.Tensor):
+                return engine.to_host(S, float_cpu())
+        return S
+
     def llr_NvsM(self, x1, x2, ids1=None, ids2=None, method="vavg-lnorm"):
         """Multi-session scoring (plda_base.py:292-322).  numpy in / numpy out; device tensors in
         (methods vavg, vavg-lnorm, savg) give a device tensor out."""
@@ -310,7 +334,7 @@ class PLDABase(HypModel):
         if method == "book":
             D1 = x1 if ids1 is None else self._stats_dev(x1, ids1)
             D2 = x2 if ids2 is None else self._stats_dev(x2, ids2)
-            return self.llr_NvsM_book(D1, D2)
+            return self._book_result(self.llr_NvsM_book(D1, D2), (x1, ids1), (x2, ids2))
         if method not in ("vavg", "vavg-lnorm"):
             raise ValueError("unknown pooling method %r" % (method,))
         plan = self.score_plan(lnorm_first=(method == "vavg-lnorm"))
@@ -323,8 +347,8 @@ class PLDABase(HypModel):
             return self._llr_savg(x1, ids1, x2, None)
         if method == "book":
             D1 = x1 if ids1 is None else self._stats_dev(x1, ids1)
-            D2 = self._stats_dev(x2, np.arange(np.asarray(x2).shape[0]))
-            return self.llr_NvsM_book(D1, D2)
+            D2 = self._stats_dev(x2, np.arange(x2.shape[0]))
+            return self._book_result(self.llr_NvsM_book(D1, D2), (x1, ids1), (x2, 0))
         if method not in ("vavg", "vavg-lnorm"):
             raise ValueError("unknown pooling method %r" % (method,))
         plan = self.score_plan(lnorm_first=(method == "vavg-lnorm"))
@@ -351,7 +375,8 @@ class PLDABase(HypModel):
 
     def llr_NvsM_book(self, D1, D2):
         """By-the-book multi-session scoring (splda.py:318-379, frplda.py:305-366,
-        plda.py:474-539) from statistics D = (N, F, S).
+        plda.py:474-539) from statistics D = (N, F, S); F as device tensors on both sides gives a
+        device matrix back.
 
         Every count n needs L(n) = I + n VV (or B + n W); instead of one Cholesky per count the
         first-order statistics are projected once onto the eigen-basis that diagonalises all L(n)
@@ -359,9 +384,15 @@ class PLDABase(HypModel):
         caller's F is not modified (the reference subtracts N mu from it in place)."""
         torch = engine.require_gpu()
         lib = _lib.load()
-        bf = self._book_fold()
+        bf = self._book_fold_cached()
         K = bf["P"].shape[1]
         kp = lib.hypmi_packed_width(K)
+        # the result first: a cached block of that size, if the allocator holds one, is then not cut
+        # up for the small temporaries below
+        n1, n2 = len(D1[0]), len(D2[0])
+        ldo = engine.round_up(max(n2, 1), 32)
+        one_block = len(np.unique(D1[0])) == 1 and len(np.unique(D2[0])) == 1
+        out = (torch.empty if one_block else torch.zeros)((n1, ldo), dtype=torch.float32, device="cuda")
         sides = []
         for D in (D1, D2):
             N = np.asarray(D[0], dtype=np.float64)
@@ -384,9 +415,6 @@ class PLDABase(HypModel):
                                             None, K, engine._ptr(s), lds_, engine.stream_ptr()))
             sides.append((N, s))
         (N1, s1), (N2, s2) = sides
-        n1, n2 = len(N1), len(N2)
-        ldo = engine.round_up(max(n2, 1), 32)
-        out = torch.zeros((n1, ldo), dtype=torch.float32, device="cuda")
         lam = bf["lam"]
 
         def vec(a):
@@ -420,6 +448,8 @@ class PLDABase(HypModel):
                                                        engine._ptr(Gs[0][1]), len(i),
                                                        engine._ptr(Gs[1][1]), len(j), engine._ptr(out),
                                                        ldo, engine.stream_ptr()))
+        if all(isinstance(D[1], torch.Tensor) for D in (D1, D2)):
+            return out[:, :n2]  # device statistics in, device scores out
         return engine.to_host(out[:, :n2], float_cpu())
 
     def get_config(self):
