@@ -120,6 +120,23 @@ def cpu_baseline(cfg, chain, model, sample):
                       % (n, n, n, dt)}
 
 
+def cpu_baseline_asnorm(cfg, chain, model, n_enrol=1000, n_test=4000):
+    """The float64 oracle on the host for the AS-norm workloads: chain + SPLDA scores of a slice
+    against the full cohort, then the reference's adaptive S-norm loops."""
+    from oracle import plda_ref as O
+
+    nc, nbest = cfg["n_coh"], cfg["nbest"]
+    ne, nt = min(n_enrol, cfg["n_enrol"]), min(n_test, cfg["n_test"])
+    xe, xt, xc = (make_inputs(cfg, n, seed).astype(np.float64) for n, seed in ((ne, 41), (nt, 43), (nc, 42)))
+    t0 = time.perf_counter()
+    ye, yt, yc = (O.chain_predict(x, chain) for x in (xe, xt, xc))
+    O.adapt_s_norm(O.llr_1vs1(model, ye, yt), O.llr_1vs1(model, yc, yt), O.llr_1vs1(model, ye, yc), nbest, 0)
+    dt = time.perf_counter() - t0
+    return {"value": ne * nt / dt, "unit": "scores/s", "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count())),
+            "kind": "port", "sample": "%d enrol x %d test against the %d cohort (chain + SPLDA + AdaptSNorm, "
+            "float64 numpy), %.2f s" % (ne, nt, nc, dt)}
+
+
 def profiled_traffic(workload):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 counter passes
     (FETCH_SIZE / WRITE_SIZE, corrected; see tools/summarize_prof.py), or None when no profile of
@@ -466,6 +483,11 @@ def main_asnorm(args, cfg, chain, model, plda, preproc, plan, world, rank, dist)
         out["sink"] = st["sink"]
     if rank == 0 and not args.no_check and chain is not None:
         out["parity"] = {"max_err_over_max_abs_1": asnorm_check(be, bufs, chain, model, cfg)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and chain is not None:
+        try:
+            out["cpu_baseline"] = cpu_baseline_asnorm(cfg, chain, model)
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
