@@ -44,3 +44,16 @@ start = torch.randint(0, a.nc - 8 * k8, (1, a.lists, 1), device="cuda", generato
 seq = start + (torch.arange(k8, device="cuda", dtype=torch.int32).view(-1, 1, 1) * 8
                + torch.arange(8, device="cuda", dtype=torch.int32).view(1, 1, -1))
 timed(seq.to(torch.int16), "consecutive from random c")
+
+# the same random lists, each ordered by LDS bank pair (c mod 32 for 8-byte elements) and rotated by a
+# lane-dependent offset, so that the 32 lanes of a half wave read 32 different bank pairs at each step
+flat = torch.randint(0, a.nc, (a.lists, 8 * k8), device="cuda", generator=g, dtype=torch.int32)
+timed(flat.reshape(a.lists, k8, 8).permute(1, 0, 2).contiguous().to(torch.int16), "random unsorted lists")
+order = torch.argsort(flat % 32, dim=1, stable=True)
+by_bank = torch.gather(flat, 1, order)[:, :a.k]
+rot = (torch.arange(a.lists, device="cuda") % 32) * a.k // 32
+pos = (torch.arange(a.k, device="cuda").view(1, -1) + rot.view(-1, 1)) % a.k
+rotated = torch.gather(by_bank, 1, pos)
+pad = torch.zeros((a.lists, 8 * k8 - a.k), device="cuda", dtype=torch.int32)
+rotated = torch.cat([rotated, pad], dim=1)
+timed(rotated.reshape(a.lists, k8, 8).permute(1, 0, 2).contiguous().to(torch.int16), "bank-ordered, lane-rotated")
