@@ -1,9 +1,10 @@
 """Read specifiers `scp[,options]:file` -> reader objects (hyperion/io/rw_specifiers.py:323-420,
-hyperion/io/data_rw_factory.py:139-173).  Ark archives behind scp files are supported; HDF5 needs
-h5py, which this build does not have."""
+hyperion/io/data_rw_factory.py:139-173): ark archives behind scp files, HDF5 files, and scp files
+over HDF5 files (the HDF5 side through the package's own reader)."""
 import re
 
 from .ark import RandomAccessArkDataReader
+from .h5 import RandomAccessH5FileDataReader, RandomAccessH5ScriptDataReader
 
 
 class RandomAccessDataReaderFactory(object):
@@ -42,7 +43,10 @@ class RandomAccessDataReaderFactory(object):
                                              scp_sep=scp_sep)
         if kind == "ark":
             raise ValueError("Random access to Ark file %s needs a script file" % path)
-        raise NotImplementedError("HDF5 vector files need h5py, which is not available; use scp:... over ark files")
+        if kind == "scp-h5":
+            return RandomAccessH5ScriptDataReader(path, path_prefix, scp_sep=scp_sep, transform=transform,
+                                                  permissive=permissive)
+        return RandomAccessH5FileDataReader(path, transform=transform, permissive=permissive)
 
     @staticmethod
     def filter_args(**kwargs):

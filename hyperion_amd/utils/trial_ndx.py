@@ -16,11 +16,17 @@ def _is_h5(file_path):
     return path.splitext(file_path)[1] in (".h5", ".hdf5")
 
 
+def _open_h5(file_path):
+    from ..io.hdf5_lite import Hdf5File
+
+    return Hdf5File(file_path)
+
+
 def _h5py():
     try:
         import h5py
     except ImportError as e:  # the text formats need nothing beyond numpy
-        raise ImportError("HDF5 trial files need h5py, which is not installed") from e
+        raise ImportError("writing HDF5 trial files needs h5py, which is not installed (reading does not)") from e
     return h5py
 
 
@@ -187,10 +193,11 @@ class TrialNdx(TrialTable):
 
     @classmethod
     def load_h5(cls, file_path):
-        with _h5py().File(file_path, "r") as f:
-            model_set = [t.decode("utf-8") for t in f["ID/row_ids"]]
-            seg_set = [t.decode("utf-8") for t in f["ID/column_ids"]]
-            trial_mask = np.asarray(f["trial_mask"], dtype=bool)
+        """trial_ndx.py:110-124, through the package's HDF5 reader."""
+        f = _open_h5(file_path)
+        model_set = [t.decode("utf-8") for t in f["ID/row_ids"]]
+        seg_set = [t.decode("utf-8") for t in f["ID/column_ids"]]
+        trial_mask = np.asarray(f["trial_mask"], dtype=bool)
         return cls(model_set, seg_set, trial_mask)
 
     @classmethod
@@ -325,14 +332,15 @@ class TrialKey(TrialTable):
 
     @classmethod
     def load_h5(cls, file_path):
-        with _h5py().File(file_path, "r") as f:
-            model_set = [t.decode("utf-8") for t in f["ID/row_ids"]]
-            seg_set = [t.decode("utf-8") for t in f["ID/column_ids"]]
-            mask = np.asarray(f["trial_mask"], dtype="int8")
-            opt = {n: (np.asarray(f[n], dtype=bool) if n in f else None)
-                   for n in ("model_cond", "seg_cond", "trial_cond")}
-            names = {n: (np.asarray(f[n], dtype="U") if n in f else None)
-                     for n in ("model_cond_name", "seg_cond_name", "trial_cond_name")}
+        """trial_key.py:163-211, through the package's HDF5 reader."""
+        f = _open_h5(file_path)
+        model_set = [t.decode("utf-8") for t in f["ID/row_ids"]]
+        seg_set = [t.decode("utf-8") for t in f["ID/column_ids"]]
+        mask = np.asarray(f["trial_mask"], dtype="int8")
+        opt = {n: (np.asarray(f[n], dtype=bool) if n in f else None)
+               for n in ("model_cond", "seg_cond", "trial_cond")}
+        names = {n: (np.asarray(f[n], dtype="U") if n in f else None)
+                 for n in ("model_cond_name", "seg_cond_name", "trial_cond_name")}
         return cls(model_set, seg_set, mask > 0, mask < 0, opt["model_cond"], opt["seg_cond"],
                    opt["trial_cond"], names["model_cond_name"], names["seg_cond_name"], names["trial_cond_name"])
 

@@ -4,7 +4,7 @@ import numpy as np
 
 from ..hyp_defs import float_cpu
 from .list_utils import split_list
-from .trial_ndx import TrialNdx, TrialTable, _h5py, _ids_and_positions, _is_h5, _read_columns
+from .trial_ndx import TrialNdx, TrialTable, _h5py, _ids_and_positions, _is_h5, _open_h5, _read_columns
 
 
 class TrialScores(TrialTable):
@@ -60,11 +60,11 @@ class TrialScores(TrialTable):
 
     @classmethod
     def load_h5(cls, file_path):
-        with _h5py().File(file_path, "r") as f:
-            model_set = [t.decode("utf-8") for t in f["ID/row_ids"]]
-            seg_set = [t.decode("utf-8") for t in f["ID/column_ids"]]
-            scores = np.asarray(f["scores"], dtype=float_cpu())
-            score_mask = np.asarray(f["score_mask"], dtype=bool)
+        f = _open_h5(file_path)
+        model_set = [t.decode("utf-8") for t in f["ID/row_ids"]]
+        seg_set = [t.decode("utf-8") for t in f["ID/column_ids"]]
+        scores = np.asarray(f["scores"], dtype=float_cpu())
+        score_mask = np.asarray(f["score_mask"], dtype=bool)
         return cls(model_set, seg_set, scores, score_mask)
 
     @classmethod
