@@ -9,6 +9,8 @@ class FRPLDA(PLDABase):
     [x_dim, x_dim] precisions and y_dim = x_dim (constructor as hyperion/pdfs/plda/frplda.py:14-39).
     """
 
+    _param_names = ("mu", "B", "W")
+
     def __init__(self, mu=None, B=None, W=None, fullcov_W=True, update_mu=True, update_B=True,
                  update_W=True, **kwargs):
         super().__init__(mu=mu, update_mu=update_mu, **kwargs)

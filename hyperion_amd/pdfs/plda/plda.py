@@ -10,6 +10,8 @@ class PLDA(PLDABase):
     subspace only enters through the Woodbury form of the within-class precision, which the host
     folds into the same two projections SPLDA uses."""
 
+    _param_names = ("mu", "V", "U", "D")
+
     def __init__(self, y_dim=None, z_dim=None, mu=None, V=None, U=None, D=None, floor_iD=1e-5,
                  update_mu=True, update_V=True, update_U=True, update_D=True, **kwargs):
         super().__init__(y_dim=y_dim, mu=mu, update_mu=update_mu, **kwargs)

@@ -92,6 +92,17 @@ class PLDABase(HypModel):
         self._plans = {}
         self._book_cache = (None, None)
 
+    _param_names = ()
+
+    @classmethod
+    def load_params(cls, f, config):
+        """Parameters from an open model file; the configuration entries are constructor
+        arguments (e.g. hyperion/pdfs/plda/splda.py:257-262)."""
+        params = cls._load_params_to_dict(f, config["name"], list(cls._param_names))
+        kwargs = dict(list(config.items()) + list(params.items()))
+        kwargs.pop("class_name", None)
+        return cls(**kwargs)
+
     # ---- to be provided by the concrete model ---------------------------------------------
     def _params(self):
         raise NotImplementedError

@@ -10,6 +10,8 @@ class SPLDA(PLDABase):
     """Simplified PLDA: x = mu + y V + e, e ~ N(0, W^-1).  V is [y_dim, x_dim], W the within-class
     precision [x_dim, x_dim] (constructor as hyperion/pdfs/plda/splda.py:13-39)."""
 
+    _param_names = ("mu", "V", "W")
+
     def __init__(self, y_dim=None, mu=None, V=None, W=None, fullcov_W=True, update_mu=True,
                  update_V=True, update_W=True, **kwargs):
         super().__init__(y_dim=y_dim, mu=mu, update_mu=update_mu, **kwargs)

@@ -29,6 +29,12 @@ class AffineTransform(HypModel):
     def predict(self, x):
         return run_chain([self], x)
 
+    @classmethod
+    def load_params(cls, f, config):
+        """mu and T from an open model file (e.g. hyperion/transforms/cent_whiten.py:73-77)."""
+        params = cls._load_params_to_dict(f, config["name"], ["mu", "T"])
+        return cls(mu=params["mu"], T=params["T"], name=config["name"])
+
 
 def chain_plan(transforms, d_in, cache_owner):
     key = (d_in,) + tuple(t._params_key() for t in transforms)

@@ -58,6 +58,12 @@ class PCA(AffineTransform):
             V = V[:, :self.pca_dim]
         self.T = V
 
+    @classmethod
+    def load_params(cls, f, config):
+        """hyperion/transforms/pca.py:120-129."""
+        params = cls._load_params_to_dict(f, config["name"], ["mu", "T"])
+        return cls(mu=params["mu"], T=params["T"], pca_dim=config.get("pca_dim"), name=config["name"])
+
     def get_config(self):
         config = {"update_mu": self.update_mu, "update_t": self.update_T, "pca_dim": self.pca_dim,
                   "pca_var_r": self.pca_var_r}

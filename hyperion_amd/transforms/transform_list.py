@@ -32,6 +32,21 @@ class TransformList(HypModel):
             return x
         return run_chain(self.transforms, x, cache_owner=self)
 
+    @classmethod
+    def load_params(cls, f, config):
+        """Every transform of the list from its own group of the file
+        (hyperion/transforms/transform_list.py:63-73)."""
+        from . import CentWhiten, LDA, LNorm, PCA
+
+        classes = {"CentWhiten": CentWhiten, "LNorm": LNorm, "LDA": LDA, "PCA": PCA}
+        transforms = []
+        for i in range(len(config["transforms"])):
+            config_t = config["transforms"][str(i)]
+            if config_t["class_name"] not in classes:
+                raise NotImplementedError("transform %s is not part of this package" % config_t["class_name"])
+            transforms.append(classes[config_t["class_name"]].load_params(f, config_t))
+        return cls(transforms, name=config["name"])
+
     def get_config(self):
         config = super().get_config()
         config["transforms"] = {i: t.get_config() for i, t in enumerate(self.transforms)}

@@ -110,3 +110,87 @@ def test_vector_reader_interfaces_on_a_real_file(tmp_path):
     assert isinstance(s, RandomAccessH5ScriptDataReader)
     assert np.array_equal(s.read(["trial_mask"])[0], ref[2:6])
     assert np.array_equal(s.read(["trial_mask"], row_offset=1, num_rows=2)[0], ref[3:5])
+
+
+def test_model_file_interfaces(tmp_path):
+    """Model files (a JSON "config" string and one float dataset per parameter,
+    hyperion/hyp_model.py:52-135) use the same file structures as the trial files above; none ships
+    with the reference, so only the pieces that can be exercised on those are: parameter look-up
+    with and without a name prefix, missing parameters, and the JSON-text fall-back of load_config."""
+    from hyperion_amd.helpers.plda_factory import PLDAFactory
+    from hyperion_amd.hyp_model import HypModel
+    from hyperion_amd.pdfs.plda import SPLDA
+    from hyperion_amd.transforms import LDA, TransformList
+
+    f = Hdf5File(NDX)
+    p = HypModel._load_params_to_dict(f, None, ["trial_mask", "absent"])
+    assert p["absent"] is None and p["trial_mask"].dtype == np.float64 and p["trial_mask"].shape == (580, 712)
+    assert HypModel._load_params_to_dict(f, "ID", ["absent"]) == {"absent": None}
+    text = tmp_path / "config.json"
+    text.write_text('{"class_name": "LDA", "name": "lda", "lda_dim": 3}')
+    assert LDA.load_config(str(text))["lda_dim"] == 3
+    with pytest.raises(KeyError):
+        SPLDA.load(NDX)  # an HDF5 file without a "config" dataset
+    with pytest.raises(ValueError):
+        PLDAFactory.load_plda("other", NDX)
+    assert isinstance(PLDAFactory.create_plda("splda", y_dim=3), SPLDA)
+    with pytest.raises(NotImplementedError):
+        TransformList.load_params(f, {"name": None, "transforms": {"0": {"class_name": "NAP", "name": "nap"}}})
+
+
+def test_models_load_from_files_with_the_reference_layout(tmp_path):
+    """A TransformList and an SPLDA model laid out as the reference saves them (config JSON string +
+    `name/parameter` float datasets, float32 as float_save() makes them), written by the test's own
+    fixture writer: configuration handling, name prefixes, float32 -> float64, nested groups."""
+    import json
+
+    from h5_fixture import nested, write_h5
+    from hyperion_amd.helpers.plda_factory import PLDAFactory
+    from hyperion_amd.transforms import LDA, CentWhiten, LNorm, TransformList
+
+    rng = np.random.RandomState(0)
+    mu, T = rng.randn(6).astype(np.float32), rng.randn(6, 6).astype(np.float32)
+    Tl = rng.randn(6, 3).astype(np.float32)
+    config = {"class_name": "TransformList", "name": None, "transforms": {
+        "0": {"class_name": "CentWhiten", "name": "cw"}, "1": {"class_name": "LNorm", "name": "ln"},
+        "2": {"class_name": "LDA", "name": "lda", "lda_dim": 3, "update_mu": True, "update_t": True}}}
+    path = str(tmp_path / "preproc.h5")
+    write_h5(path, nested({"config": np.array(json.dumps(config)), "cw/mu": mu, "cw/T": T, "lda/T": Tl}))
+    f = Hdf5File(path)
+    assert f.keys() == ["config", "cw", "lda"] and np.array_equal(f["cw/T"], T) and f["cw/T"].dtype == np.float32
+    t = TransformList.load(path)
+    assert [type(x) for x in t.transforms] == [CentWhiten, LNorm, LDA]
+    assert t.transforms[0].mu.dtype == np.float64 and np.array_equal(t.transforms[0].T, T.astype(np.float64))
+    assert t.transforms[1].mu is None and t.transforms[1].T is None
+    assert t.transforms[2].mu is None and t.transforms[2].lda_dim == 3
+    assert TransformList.load_config(path)["transforms"]["2"]["lda_dim"] == 3
+
+    V, W = rng.randn(2, 6), np.eye(6) + 0.1 * np.ones((6, 6))
+    cfg = {"class_name": "SPLDA", "name": "plda", "y_dim": 2, "update_mu": True, "update_W": True,
+           "update_V": False, "fullcov_W": True}
+    path = str(tmp_path / "plda.h5")
+    write_h5(path, nested({"config": np.array(json.dumps(cfg)), "plda/mu": mu, "plda/V": V, "plda/W": W}))
+    m = PLDAFactory.load_plda("splda", path)
+    assert m.name == "plda" and m.y_dim == 2 and m.update_V is False and np.array_equal(m.V, V)
+    assert m.is_init and m.x_dim == 6
+
+
+def test_vector_file_with_one_dataset_per_key(tmp_path):
+    """The layout of the reference's H5DataWriter (hyperion/io/h5_data_writer.py): every key a
+    dataset, keys with "/" nested groups; float32 on disk, float_cpu() out."""
+    from h5_fixture import nested, write_h5
+    from hyperion_amd.io import RandomAccessDataReaderFactory as F
+
+    rng = np.random.RandomState(1)
+    vecs = {"spk1/utt-a": rng.randn(5), "spk1/utt-b": rng.randn(5), "spk2/utt-c": rng.randn(5), "solo": rng.randn(5)}
+    path = str(tmp_path / "xvector.h5")
+    write_h5(path, nested({k: v.astype(np.float32) for k, v in vecs.items()}))
+    r = F.create(path)
+    keys = ["solo", "spk2/utt-c", "spk1/utt-a"]
+    x = r.read(keys, squeeze=True)
+    assert x.shape == (3, 5) and x.dtype == np.float64
+    assert np.array_equal(x, np.stack([vecs[k].astype(np.float32) for k in keys]).astype(np.float64))
+    assert r.read_dims(keys).tolist() == [5, 5, 5]
+    p = F.create("h5,p:" + path)
+    y = p.read(["solo", "spk9/none"], squeeze=True)
+    assert y.shape == (2, 5) and not y[1].any()
