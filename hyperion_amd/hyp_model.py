@@ -1,13 +1,14 @@
 """Base class of the host API objects: a name plus a JSON-able config, and loading of the HDF5
 model files the reference writes (hyperion/hyp_model.py:17-135: a "config" JSON string plus one
-float dataset per parameter under the object's name).  Reading goes through the package's own HDF5
-parser; writing model files is not provided."""
+float dataset per parameter under the object's name).  Reading and writing go through the package's
+own HDF5 parser and writer (hyperion_amd/io/hdf5_lite.py, hdf5_write.py); h5py is not needed."""
 import json
+import os
 import zlib
 
 import numpy as np
 
-from .hyp_defs import float_cpu
+from .hyp_defs import float_cpu, float_save
 
 
 class HypModel(object):
@@ -22,7 +23,44 @@ class HypModel(object):
     def get_config(self):
         return {"class_name": self.__class__.__name__, "name": self.name}
 
-    # ---- model files (hyperion/hyp_model.py:86-135) --------------------------------------------
+    def to_json(self, **kwargs):
+        """The configuration as JSON text; numpy scalars become Python numbers, types their names
+        (hyperion/hyp_model.py:117-131)."""
+        def get_json_type(obj):
+            if type(obj).__module__ == np.__name__:
+                return obj.item()
+            if type(obj).__name__ == type.__name__:
+                return obj.__name__
+            raise TypeError("Not JSON Serializable:", obj)
+
+        return json.dumps(self.get_config(), default=get_json_type, **kwargs)
+
+    # ---- model files (hyperion/hyp_model.py:44-135) --------------------------------------------
+    def save(self, file_path):
+        """Writes the model file the reference writes: a scalar string dataset "config" with the
+        JSON configuration, then the parameters (hyperion/hyp_model.py:44-52)."""
+        from .io.hdf5_write import File
+
+        file_dir = os.path.dirname(file_path)
+        if file_dir and not os.path.isdir(file_dir):
+            os.makedirs(file_dir, exist_ok=True)
+        with File(file_path, "w") as f:
+            f.create_dataset("config", data=np.array(self.to_json(), dtype="S"))
+            self.save_params(f)
+
+    def save_params(self, f):
+        """Models without parameters write nothing beyond the configuration."""
+
+    def _save_params_from_dict(self, f, params, dtypes=None):
+        """One dataset `name/parameter` per array that is not None, stored as float_save()
+        unless `dtypes` says otherwise (hyperion/hyp_model.py:58-73)."""
+        prefix = "" if self.name is None else self.name + "/"
+        for k, v in params.items():
+            if v is None:
+                continue
+            dtype = float_save() if dtypes is None else dtypes[k]
+            f.create_dataset(prefix + k, data=np.asarray(v).astype(dtype, copy=False))
+
     @staticmethod
     def _config_of(f):
         return json.loads(str(np.asarray(f["config"]).astype("U")))

@@ -1,10 +1,12 @@
 """HDF5 vector / matrix files: one dataset per key (hyperion/io/h5_data_reader.py:403-760,
-h5_data_writer.py), read through the package's own HDF5 parser (hdf5_lite; h5py is not needed).
-Keys with "/" are nested groups, as h5py stores them.  Datasets with the Kaldi compression
-attributes ("data_format") are not supported."""
+h5_data_writer.py), read and written through the package's own HDF5 parser and writer (hdf5_lite,
+hdf5_write; h5py is not needed).  Keys with "/" are nested groups, as h5py stores them.  Datasets
+with the Kaldi compression attributes ("data_format") are not supported."""
+import os
+
 import numpy as np
 
-from ..hyp_defs import float_cpu
+from ..hyp_defs import float_cpu, float_save
 from .ark import RandomAccessArkDataReader
 from .hdf5_lite import Hdf5File
 
@@ -156,3 +158,56 @@ class RandomAccessH5ScriptDataReader(_H5ReaderBase):
             first.append(a)
             count.append(b)
         return super().read(keys, squeeze, first, count)
+
+
+class H5DataWriter(object):
+    """One float_save() dataset per key and, optionally, a script line `key file.h5` for each
+    (hyperion/io/h5_data_writer.py:17-130); uncompressed only."""
+
+    def __init__(self, archive_path, script_path=None, flush=False, compress=False, compression_method="auto",
+                 scp_sep=" ", **kwargs):
+        if compress:
+            raise NotImplementedError("Kaldi-compressed HDF5 datasets are not written")
+        from .hdf5_write import File
+
+        self.archive_path, self.script_path, self.scp_sep, self._flush = archive_path, script_path, scp_sep, flush
+        for p in (archive_path, script_path):
+            d = os.path.dirname(p) if p else ""
+            if d and not os.path.exists(d):
+                os.makedirs(d)
+        self.f = File(archive_path, "w")
+        self.f_script = open(script_path, "w") if script_path is not None else None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def close(self):
+        if self.f is not None:
+            self.f.close()
+            self.f = None
+        if self.f_script is not None:
+            self.f_script.close()
+            self.f_script = None
+
+    def flush(self):
+        self.f.flush()
+        if self.f_script is not None:
+            self.f_script.flush()
+
+    def write(self, keys, data):
+        """keys: names (no white space); data: list of vectors / matrices, or a 2-D / 3-D array
+        whose first axis runs over the keys."""
+        if isinstance(keys, str):
+            keys, data = [keys], [data]
+        for key, x in zip(keys, data):
+            assert len(key) > 0 and not any(c.isspace() for c in key), "Token %s not valid" % key
+            if not isinstance(x, np.ndarray):
+                raise ValueError("Data is not ndarray")
+            self.f.create_dataset(key, data=x.astype(float_save(), copy=False))
+            if self.f_script is not None:
+                self.f_script.write("%s%s%s\n" % (key, self.scp_sep, self.archive_path))
+        if self._flush:
+            self.flush()

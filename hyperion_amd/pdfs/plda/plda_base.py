@@ -94,6 +94,10 @@ class PLDABase(HypModel):
 
     _param_names = ()
 
+    def save_params(self, f):
+        """The parameters named by `_param_names`, e.g. mu, V, W (hyperion/pdfs/plda/splda.py:253-255)."""
+        self._save_params_from_dict(f, {k: getattr(self, k) for k in self._param_names})
+
     @classmethod
     def load_params(cls, f, config):
         """Parameters from an open model file; the configuration entries are constructor

@@ -29,6 +29,10 @@ class AffineTransform(HypModel):
     def predict(self, x):
         return run_chain([self], x)
 
+    def save_params(self, f):
+        """mu and T under the transform's name (e.g. hyperion/transforms/cent_whiten.py:69-71)."""
+        self._save_params_from_dict(f, {"mu": self.mu, "T": self.T})
+
     @classmethod
     def load_params(cls, f, config):
         """mu and T from an open model file (e.g. hyperion/transforms/cent_whiten.py:73-77)."""

@@ -32,6 +32,11 @@ class TransformList(HypModel):
             return x
         return run_chain(self.transforms, x, cache_owner=self)
 
+    def save_params(self, f):
+        """hyperion/transforms/transform_list.py:58-60."""
+        for t in self.transforms:
+            t.save_params(f)
+
     @classmethod
     def load_params(cls, f, config):
         """Every transform of the list from its own group of the file

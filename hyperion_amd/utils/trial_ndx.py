@@ -22,12 +22,11 @@ def _open_h5(file_path):
     return Hdf5File(file_path)
 
 
-def _h5py():
-    try:
-        import h5py
-    except ImportError as e:  # the text formats need nothing beyond numpy
-        raise ImportError("writing HDF5 trial files needs h5py, which is not installed (reading does not)") from e
-    return h5py
+def _h5_writer(file_path):
+    """An object with h5py's `create_dataset(name, data=...)`, from the package's own HDF5 writer."""
+    from ..io.hdf5_write import File
+
+    return File(file_path, "w")
 
 
 def _read_columns(file_path, num_fields):
@@ -176,7 +175,7 @@ class TrialNdx(TrialTable):
 
     def save_h5(self, file_path):
         """Datasets ID/row_ids, ID/column_ids, trial_mask (trial_ndx.py:61-72)."""
-        with _h5py().File(file_path, "w") as f:
+        with _h5_writer(file_path) as f:
             f.create_dataset("ID/row_ids", data=self.model_set.astype("S"))
             f.create_dataset("ID/column_ids", data=self.seg_set.astype("S"))
             f.create_dataset("trial_mask", data=self.trial_mask.astype("uint8"))
@@ -307,7 +306,7 @@ class TrialKey(TrialTable):
 
     def save_h5(self, file_path):
         """trial_mask = +1 target, -1 non-target (trial_key.py:98-126)."""
-        with _h5py().File(file_path, "w") as f:
+        with _h5_writer(file_path) as f:
             f.create_dataset("ID/row_ids", data=self.model_set.astype("S"))
             f.create_dataset("ID/column_ids", data=self.seg_set.astype("S"))
             f.create_dataset("trial_mask", data=self.tar.astype("int8") - self.non.astype("int8"))

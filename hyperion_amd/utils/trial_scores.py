@@ -4,7 +4,7 @@ import numpy as np
 
 from ..hyp_defs import float_cpu
 from .list_utils import split_list
-from .trial_ndx import TrialNdx, TrialTable, _h5py, _ids_and_positions, _is_h5, _open_h5, _read_columns
+from .trial_ndx import TrialNdx, TrialTable, _h5_writer, _ids_and_positions, _is_h5, _open_h5, _read_columns
 
 
 class TrialScores(TrialTable):
@@ -38,7 +38,7 @@ class TrialScores(TrialTable):
         (self.save_h5 if _is_h5(file_path) else self.save_txt)(file_path)
 
     def save_h5(self, file_path):
-        with _h5py().File(file_path, "w") as f:
+        with _h5_writer(file_path) as f:
             f.create_dataset("ID/row_ids", data=self.model_set.astype("S"))
             f.create_dataset("ID/column_ids", data=self.seg_set.astype("S"))
             f.create_dataset("scores", data=self.scores)
