@@ -5,6 +5,7 @@ own HDF5 parser and writer (hyperion_amd/io/hdf5_lite.py, hdf5_write.py); h5py i
 import json
 import os
 import zlib
+from copy import deepcopy
 
 import numpy as np
 
@@ -16,9 +17,27 @@ class HypModel(object):
         self.name = name
         self._is_init = False
 
+    # attributes that hold device plans or other values derived from the parameters -> factory of
+    # their empty value; they are rebuilt on first use and never copied or pickled
+    _cache_defaults = {}
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        for k, make in self._cache_defaults.items():
+            if k in state:
+                state[k] = make()
+        return state
+
+    def copy(self):
+        """An independent model with the same parameters (hyperion/hyp_model.py:23-24)."""
+        return deepcopy(self)
+
     @property
     def is_init(self):
         return self._is_init
+
+    def init_to_false(self):
+        self._is_init = False
 
     def get_config(self):
         return {"class_name": self.__class__.__name__, "name": self.name}

@@ -1,6 +1,7 @@
 import numpy as np
 
 from ... import fold
+from ...hyp_defs import float_cpu
 from .plda_base import PLDABase
 
 
@@ -64,6 +65,43 @@ class PLDA(PLDABase):
         K = P.shape[1]
         return {"P": P, "row_bias": -(mu @ P), "shift_t": np.zeros(K), "shift_n": np.zeros(K),
                 "lam": lam, "c_extra": 0.0}
+
+    # ---- sampling, adaptation (plda.py:541-589) --------------------------------------------------
+    def sample(self, num_classes, num_samples_per_class, rng=None, seed=1024):
+        """Host draw with numpy's generator, in the reference's order; the residual is divided by D
+        itself, as it is there (plda.py:541-562)."""
+        if rng is None:
+            rng = np.random.RandomState(seed=seed)
+        f = lambda a: np.asarray(a, dtype=np.float64)  # noqa: E731
+        mu, V, U, D = f(self.mu), f(self.V), f(self.U), f(self.D)
+        n, d = num_classes * num_samples_per_class, mu.shape[0]
+        z1 = rng.normal(size=(n, d)).astype(float_cpu(), copy=False) / D
+        z2 = rng.normal(size=(n, self.z_dim)).astype(float_cpu(), copy=False) @ U
+        y = rng.normal(size=(num_classes, self.y_dim)).astype(float_cpu(), copy=False) @ V + mu
+        return np.repeat(y, num_samples_per_class, axis=0) + z1 + z2
+
+    def weighted_avg_params(self, mu, V, U, D, w_mu, w_B, w_W):
+        """Interpolation towards (mu, V, U, D): between-class covariance V^T V refactored to y_dim
+        directions; within-class covariance U^T U + diag(1 / D) refactored to z_dim directions plus
+        a floored diagonal (plda.py:564-589)."""
+        from scipy import linalg as sla
+
+        f = lambda a: np.asarray(a, dtype=np.float64)  # noqa: E731
+        self.weigthed_avg_params(mu, w_mu)
+        if w_B > 0:
+            w, E = sla.eigh(w_B * (f(V).T @ f(V)) + (1 - w_B) * (f(self.V).T @ f(self.V)))
+            self.V = (np.sqrt(w) * E)[:, -self.y_dim:].T
+        if w_W > 0:
+            Sw0 = f(self.U).T @ f(self.U) + np.diag(1 / f(self.D))
+            Sw = w_W * (f(U).T @ f(U) + np.diag(1 / f(D))) + (1 - w_W) * Sw0
+            w, E = sla.eigh(Sw)
+            self.U = (np.sqrt(w) * E)[:, -self.z_dim:].T
+            iD = np.diag(Sw - self.U.T @ self.U).copy()
+            iD[iD < self.floor_iD] = self.floor_iD
+            self.D = 1 / iD
+
+    def weighted_avg_model(self, plda, w_mu, w_B, w_W):
+        self.weighted_avg_params(plda.mu, plda.V, plda.U, plda.D, w_mu, w_B, w_W)
 
     def get_config(self):
         config = {"z_dim": self.z_dim, "update_V": self.update_V, "update_U": self.update_U,

@@ -93,6 +93,7 @@ class PLDABase(HypModel):
         self._book_cache = (None, None)
 
     _param_names = ()
+    _cache_defaults = {"_plans": dict, "_book_cache": lambda: (None, None)}
 
     def save_params(self, f):
         """The parameters named by `_param_names`, e.g. mu, V, W (hyperion/pdfs/plda/splda.py:253-255)."""
@@ -282,18 +283,24 @@ class PLDABase(HypModel):
         M-steps on the small accumulators.  Returns (elbo, elbo / N) per epoch, and the same for the
         validation set when one is given.  As in the reference, sample weights are accepted and not
         used (plda_base.py:56)."""
-        use_ml = ml_md != "md"
-        use_md = ml_md != "ml"
         D = self._train_stats(x, class_ids, ptheta, sample_weight)
         D_val = None
         if x_val is not None:
             D_val = self._train_stats(x_val, class_ids_val, ptheta_val, sample_weight_val)
         if not self.is_init:
             self.initialize(D)
+        return self._em_epochs(D, D_val, epochs, ml_md, md_epochs)
+
+    def _em_epochs(self, D, D_val, epochs, ml_md, md_epochs, after_epoch=None, also=None):
+        """The epoch loop shared by fit and the adaptation variants."""
+        use_ml = ml_md != "md"
+        use_md = ml_md != "ml"
         elbo = np.zeros((epochs,), dtype=float_cpu())
         elbo_val = np.zeros((epochs,), dtype=float_cpu())
         for epoch in range(epochs):
             stats = self.Estep(D)
+            if also is not None:
+                self.Estep(also)
             elbo[epoch] = self.elbo(stats)
             if D_val is not None:
                 elbo_val[epoch] = self.elbo(self.Estep(D_val))
@@ -301,10 +308,44 @@ class PLDABase(HypModel):
                 self.MstepML(stats)
             if use_md and (md_epochs is None or epoch in md_epochs):
                 self.MstepMD(stats)
+            if after_epoch is not None:
+                after_epoch()
         elbo_norm = elbo / np.sum(D.N)
         if D_val is None:
             return elbo, elbo_norm
         return elbo, elbo_norm, elbo_val, elbo_val / np.sum(D_val.N)
+
+    @engine.small_host_algebra
+    def fit_adapt_weighted_avg_model(self, x, class_ids=None, ptheta=None, sample_weight=None, x_val=None,
+                                     class_ids_val=None, ptheta_val=None, sample_weight_val=None, epochs=20,
+                                     ml_md="ml+md", md_epochs=None, plda0=None, w_mu=1, w_B=0.5, w_W=0.5):
+        """EM on adaptation data from the current model, pulled back towards `plda0` after every
+        epoch by weighted_avg_model (plda_base.py:111-167)."""
+        assert self.is_init
+        D = self._train_stats(x, class_ids, ptheta, sample_weight)
+        D_val = None if x_val is None else self._train_stats(x_val, class_ids_val, ptheta_val, sample_weight_val)
+        return self._em_epochs(D, D_val, epochs, ml_md, md_epochs,
+                               after_epoch=lambda: self.weighted_avg_model(plda0, w_mu, w_B, w_W))
+
+    @engine.small_host_algebra
+    def fit_adapt(self, x, class_ids=None, ptheta=None, sample_weight=None, x0=None, class_ids0=None, ptheta0=None,
+                  sample_weight0=None, x_val=None, class_ids_val=None, ptheta_val=None, sample_weight_val=None,
+                  epochs=20, ml_md="ml+md", md_epochs=None):
+        """EM on adaptation data from the current model (plda_base.py:169-235).  As there, the
+        statistics of the out-of-domain set (x0) go through the E-step every epoch and are not used
+        further, and the call needs them: without x0 the reference stops with a NameError, this
+        with an AssertionError."""
+        assert self.is_init
+        assert x0 is not None, "fit_adapt needs the out-of-domain set x0"
+        D = self._train_stats(x, class_ids, ptheta, sample_weight)
+        D0 = self._train_stats(x0, class_ids0, ptheta0, sample_weight0)
+        D_val = None if x_val is None else self._train_stats(x_val, class_ids_val, ptheta_val, sample_weight_val)
+        return self._em_epochs(D, D_val, epochs, ml_md, md_epochs, also=D0)
+
+    def weigthed_avg_params(self, mu, w_mu):
+        """The mean part of the model interpolation, under the reference's spelling
+        (plda_base.py:362-363)."""
+        self.mu = w_mu * np.asarray(mu, dtype=np.float64) + (1 - w_mu) * np.asarray(self.mu, dtype=np.float64)
 
     # ---- N vs M -----------------------------------------------------------------------------
     def _pooled_mean(self, x, ids):

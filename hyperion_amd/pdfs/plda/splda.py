@@ -241,7 +241,47 @@ class SPLDA(PLDABase):
         if self.update_V:
             self.V = sla.cholesky(Py / M - np.outer(mu_y, mu_y), lower=False) @ self.V
 
+    # ---- sampling, adaptation (splda.py:381-419) ------------------------------------------------
+    def sample(self, num_classes, num_samples_per_class, rng=None, seed=1024):
+        """Host draw with numpy's generator, in the reference's order (splda.py:381-399)."""
+        from scipy import linalg as sla
+
+        if rng is None:
+            rng = np.random.RandomState(seed=seed)
+        W, V, mu = self._W_full(), np.asarray(self.V, dtype=np.float64), np.asarray(self.mu, dtype=np.float64)
+        chol_Sw = sla.cholesky(_inv_pd(W), lower=False)
+        d = mu.shape[0]
+        z = rng.normal(size=(num_classes * num_samples_per_class, d)).astype(float_cpu(), copy=False) @ chol_Sw
+        y = rng.normal(size=(num_classes, self.y_dim)).astype(float_cpu(), copy=False) @ V + mu
+        return np.repeat(y, num_samples_per_class, axis=0) + z
+
+    def weighted_avg_params(self, mu, V, W, w_mu, w_B, w_W):
+        """Interpolation towards (mu, V, W): between-class covariance V^T V refactored to y_dim
+        directions, within-class covariance W^-1 (splda.py:401-416)."""
+        from scipy import linalg as sla
+
+        self.weigthed_avg_params(mu, w_mu)
+        if w_B > 0:
+            V0, V = np.asarray(self.V, dtype=np.float64), np.asarray(V, dtype=np.float64)
+            w, U = sla.eigh(w_B * (V.T @ V) + (1 - w_B) * (V0.T @ V0))
+            self.V = (np.sqrt(w[-self.y_dim:]) * U[:, -self.y_dim:]).T
+        if w_W > 0:
+            W = np.asarray(W, dtype=np.float64)
+            W = np.diag(W) if W.ndim == 1 else W
+            self.W = _inv_pd(w_W * _inv_pd(W) + (1 - w_W) * _inv_pd(self._W_full()))
+
+    def weighted_avg_model(self, plda, w_mu, w_B, w_W):
+        self.weighted_avg_params(plda.mu, plda.V, plda.W, w_mu, w_B, w_W)
+
     def get_config(self):
         config = {"update_W": self.update_W, "update_V": self.update_V, "fullcov_W": self.fullcov_W}
         base_config = super().get_config()
         return dict(list(base_config.items()) + list(config.items()))
+
+
+def _inv_pd(A):
+    """Inverse of a positive definite matrix through its Cholesky factor, upper triangle read
+    (hyperion/utils/math.py:38-57 with return_inv=True)."""
+    from scipy import linalg as sla
+
+    return sla.cho_solve((sla.cholesky(A, lower=False), False), np.eye(A.shape[0]))

@@ -10,6 +10,7 @@ from ..hyp_model import HypModel, fingerprint
 
 class AffineTransform(HypModel):
     _lnorm = False
+    _cache_defaults = {"_plan": lambda: None, "_plan_key": lambda: None}
 
     def __init__(self, mu=None, T=None, **kwargs):
         super().__init__(**kwargs)

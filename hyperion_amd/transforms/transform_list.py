@@ -7,6 +7,8 @@ class TransformList(HypModel):
     The whole list is folded into one device plan: consecutive affine maps are multiplied
     together on the host, so the device runs one GEMM per length-normalised segment."""
 
+    _cache_defaults = {"_plan": lambda: None, "_plan_key": lambda: None}
+
     def __init__(self, transforms, **kwargs):
         super().__init__(**kwargs)
         if not isinstance(transforms, list):

@@ -417,6 +417,121 @@ def gen_splda_training():
     print("splda training ok")
 
 
+def gen_frplda_training():
+    """FRPLDA EM training of the reference (hyperion/pdfs/plda/plda_base.py:34-88,
+    hyperion/pdfs/plda/frplda.py:49-236), its sampler, and the model interpolation used for domain
+    adaptation (splda.py:401-419, frplda.py:396-410, plda.py:564-589): the set-up of the reference's
+    own FRPLDA test (tests/hyperion/pdfs/plda/test_frplda.py:22-29) plus an 8-dimensional one with
+    ragged and weighted counts."""
+    from scipy import linalg as la
+
+    out = {}
+    mu = np.array([0.5, 0])
+    Sb = np.array([[1, 0.05], [0.05, 0.1]])
+    Sw = np.array([[0.1, 0.05], [0.05, 1]])
+    truth = {"type": "frplda", "mu": mu, "B": la.inv(Sb), "W": la.inv(Sw)}
+    r0 = ref_model(truth)
+    x2, y2 = r0.sample(50, 10, seed=1024, return_y=True)
+    xo, yo = O.plda_sample(truth, 50, 10, seed=1024, return_y=True)
+    close(xo, x2), close(yo, y2)
+    out.update(flat("t2_", truth))
+    out["t2_x"], out["t2_y"] = x2, y2
+    ids2 = np.repeat(np.arange(50), 10)
+    r = R.FRPLDA()
+    elbo, elbo_norm = r.fit(x2, ids2)
+    m, eo = O.frplda_fit(O.compute_stats_hard(x2, ids2))
+    close(eo, elbo, 1e-9), close(m["mu"], r.mu, 1e-8), close(m["B"], r.B, 1e-8), close(m["W"], r.W, 1e-8)
+    out["t2_elbo"], out["t2_elbo_norm"] = elbo, elbo_norm
+    out["t2_fit_mu"], out["t2_fit_B"], out["t2_fit_W"] = r.mu, r.B, r.W
+
+    rng = np.random.RandomState(78)
+    d, ncls = 8, 40
+    counts = rng.randint(1, 7, ncls)
+    y = np.repeat(np.arange(ncls), counts)
+    n = y.shape[0]
+    x = 1.3 * rng.randn(ncls, d)[y] * np.exp(rng.uniform(-0.5, 0.5, d)) + 0.7 * rng.randn(n, d) @ rng.randn(d, d) / 2 + 1.5
+    perm = rng.permutation(n)
+    x, y = x[perm], y[perm]
+    w = rng.uniform(0.5, 2.0, n)
+    out.update(x=x, y=y, w=w)
+    D = R.FRPLDA.compute_stats_hard(x, y)
+    Dw = R.FRPLDA.compute_stats_hard(x, y, sample_weight=w)
+    for tag, DD in (("", D), ("w_", Dw)):
+        r = R.FRPLDA()
+        r.initialize(DD)
+        out["init_" + tag + "mu"], out["init_" + tag + "B"], out["init_" + tag + "W"] = r.mu, r.B, r.W
+        for a, b in zip(O.frplda_initialize(DD), (r.mu, r.B, r.W)):
+            close(a, b)
+        m0 = {"type": "frplda", "mu": r.mu.copy(), "B": r.B.copy(), "W": r.W.copy()}
+        got = r.compute_py_g_x(DD, return_cov=True, return_logpy_0=True, return_acc=True)
+        for a, b in zip(O.frplda_compute_py_g_x(m0, DD, return_cov=True, return_logpy_0=True, return_acc=True), got):
+            close(a, b)
+        for name, v in zip(("y", "cov", "logpy", "Ry", "Py"), got):
+            out["post_" + tag + name] = v
+        st = r.Estep(DD)
+        so = O.frplda_estep(m0, DD)
+        for a, b in zip(so, st):
+            close(a, b)
+        out["elbo0_" + tag[:1]] = r.elbo(st)
+        close(O.frplda_elbo(m0, so), r.elbo(st))
+
+    setups = {
+        "a": (D, dict(epochs=6, ml_md="ml+md"), {}),
+        "b": (Dw, dict(epochs=4, ml_md="ml"), {}),
+        "c": (D, dict(epochs=5, ml_md="ml"), dict(update_mu=False)),
+        "d": (D, dict(epochs=3, ml_md="ml"), dict(update_B=False, fullcov_W=False)),
+    }
+    for tag, (DD, kw, upd) in setups.items():
+        r = R.FRPLDA(**upd)
+        if DD is D:
+            if not upd.get("update_mu", True):  # a model to keep the mean of
+                r.initialize(DD)
+                r.mu = r.mu + 0.02
+            elbo, elbo_norm = r.fit(x, class_ids=y, **kw)
+            m_start = None
+            if not upd.get("update_mu", True):
+                mu0, B0, W0 = O.frplda_initialize(DD)
+                m_start = {"type": "frplda", "mu": mu0 + 0.02, "B": B0, "W": W0}
+        else:  # fit() does not pass sample weights on (plda_base.py:56): the same loop on weighted statistics
+            r.initialize(DD)
+            elbo = np.zeros(kw["epochs"])
+            for e in range(kw["epochs"]):
+                st = r.Estep(DD)
+                elbo[e] = r.elbo(st)
+                r.MstepML(st)
+            elbo_norm = elbo / np.sum(DD[0])
+            m_start = None
+        m, eo = O.frplda_fit(DD, m=m_start, **kw, **upd)
+        close(eo, elbo, 1e-9), close(m["mu"], r.mu, 1e-8), close(m["B"], r.B, 1e-8), close(m["W"], r.W, 1e-8)
+        out["fit_%s_elbo" % tag], out["fit_%s_elbo_norm" % tag] = elbo, elbo_norm
+        out["fit_%s_mu" % tag], out["fit_%s_B" % tag], out["fit_%s_W" % tag] = r.mu, r.B, r.W
+
+    # samplers and model interpolation of the three model types
+    models = small_models(6, 3, 5)
+    others = small_models(6, 3, 6)
+    for kind in ("splda", "frplda", "plda"):
+        a, b = models[kind], others[kind]
+        out.update(flat("adapt_%s_a_" % kind, a))
+        out.update(flat("adapt_%s_b_" % kind, b))
+        ra, rb = ref_model(a), ref_model(b)
+        xs = ra.sample(4, 3, seed=11)
+        close(O.plda_sample(a, 4, 3, seed=11), xs)
+        out["sample_%s" % kind] = xs
+        ra.weighted_avg_model(rb, 0.75, 0.5, 0.25)
+        mo = O.plda_weighted_avg_model(a, b, 0.75, 0.5, 0.25)
+        for k in mo:
+            if k != "type":
+                # rows of an interpolated V / U are eigenvectors: equal up to sign
+                if k in ("V", "U"):
+                    close(np.abs(mo[k] @ mo[k].T), np.abs(getattr(ra, k) @ getattr(ra, k).T), 1e-9)
+                    close(mo[k].T @ mo[k], getattr(ra, k).T @ getattr(ra, k), 1e-9)
+                else:
+                    close(mo[k], getattr(ra, k), 1e-9)
+                out["adapt_%s_out_%s" % (kind, k)] = getattr(ra, k)
+    np.savez_compressed(os.path.join(OUT, "frplda_training.npz"), **out)
+    print("frplda training ok")
+
+
 def gen_diarization():
     """The diarization consumer of the reference (hyperion/diarization/diar_ahc_plda.py:122-168,
     hyperion/clustering/ahc.py:36-110): length normalisation, PCA fitted on the recording, projected
@@ -445,6 +560,7 @@ def gen_diarization():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    gen_frplda_training()
     gen_diarization()
     gen_splda_training()
     gen_training_stats()

@@ -619,6 +619,176 @@ def splda_fit(D, y_dim, m=None, epochs=20, ml_md="ml+md", md_epochs=None, **upda
     return m, elbo
 
 
+# ----------------------------------------------------------------------------- FRPLDA training
+def frplda_initialize(D):
+    """hyperion/pdfs/plda/frplda.py:49-75: class means for mu and the between-class covariance, the
+    scatter around them for the within-class covariance; both inverted."""
+    N, F, S = D
+    M = F.shape[0]
+    y = F / N[:, None]
+    Fy = np.dot(F.T, y)
+    C = S - Fy - Fy.T
+    for i in range(M):
+        C += N[i] * np.outer(y[i, :], y[i, :])
+    C = (C + C.T) / 2
+    mu = np.mean(y, axis=0)
+    iB = np.dot(y.T, y) / M - np.outer(mu, mu)
+    iW = C / np.sum(N)
+    return mu, inv_pdmat(iB), inv_pdmat(iW)
+
+
+def frplda_compute_py_g_x(m, D, return_cov=False, return_logpy_0=False, return_acc=False):
+    """hyperion/pdfs/plda/frplda.py:77-158: posterior N(y_i, L_i^-1), L_i = B + N_i W, of every class
+    mean; classes are visited by distinct count when all counts are whole numbers.  As there, the
+    accumulator Ry comes back as zeros (only Py gathers the posterior covariances, frplda.py:146)."""
+    N, F, _ = D
+    mu, B, W = m["mu"], m["B"], m["W"]
+    M, y_dim = F.shape
+    gamma = np.dot(F, W) + np.dot(mu, B)
+    whole = bool(np.all(np.ceil(N) == N))
+    compute_inv = return_cov or return_acc
+    y = np.zeros_like(F)
+    Sigma_y = np.zeros((M, y_dim, y_dim)) if return_cov else None
+    logpy = -0.5 * y_dim * np.log(2 * np.pi) * np.ones((M,))
+    Py, Ry = np.zeros((y_dim, y_dim)), np.zeros((y_dim, y_dim))
+    for k in (np.unique(N) if whole else range(M)):
+        if whole:
+            i = (N == k).nonzero()[0]
+            N_i, M_i = k, len(i)
+        else:
+            i, N_i, M_i = k, N[k], 1
+        R = chol_upper(B + N_i * W)
+        y[i, :] = _cho_solve_right(R, gamma[i, :])
+        if compute_inv:
+            iL = _cho_solve_right(R, np.eye(y_dim))
+        if return_cov:
+            Sigma_y[i, :, :] = iL
+        if return_logpy_0:
+            logL = 2 * np.sum(np.log(np.diag(R)))
+            logpy[i] += 0.5 * (logL - np.sum(y[i, :] * gamma[i, :], axis=-1))
+        if return_acc:
+            Py += M_i * iL
+    out = [y]
+    if return_cov:
+        out.append(Sigma_y)
+    if return_logpy_0:
+        out.append(logpy)
+    if return_acc:
+        out += [Ry, Py]
+    return out[0] if len(out) == 1 else tuple(out)
+
+
+def frplda_estep(m, D):
+    """hyperion/pdfs/plda/frplda.py:160-177: (N_tot, M, S, sum logpy, sum y, Ry, Cy = F^T y, Py)."""
+    N, F, S = D
+    y, logpy, Ry, Py = frplda_compute_py_g_x(m, D, return_logpy_0=True, return_acc=True)
+    Niy = y * N[:, None]
+    Ry = Ry + np.dot(Niy.T, y)
+    Py = Py + np.dot(y.T, y)
+    return (np.sum(N), F.shape[0], S, np.sum(logpy), np.sum(y, axis=0), Ry, np.dot(F.T, y), Py)
+
+
+def frplda_elbo(m, stats):
+    """hyperion/pdfs/plda/frplda.py:179-202."""
+    N, M, S, logpy_x = stats[:4]
+    mu, B, W = m["mu"], m["B"], m["W"]
+    d = mu.shape[0]
+    logpx_y = 0.5 * (-N * d * np.log(2 * np.pi) + N * logdet_pdmat(W) - np.inner(W.ravel(), S.ravel()))
+    logpy = 0.5 * M * (-d * np.log(2 * np.pi) + logdet_pdmat(B) - np.inner(np.dot(mu, B), mu))
+    return logpx_y + logpy - logpy_x
+
+
+def frplda_mstep_ml(m, stats, update_mu=True, update_B=True, update_W=True, fullcov_W=True):
+    """hyperion/pdfs/plda/frplda.py:216-233; returns the updated model.  With update_mu off the
+    cross term is subtracted twice un-transposed, as there (frplda.py:225-226)."""
+    N, M, S, _, y_acc, Ry, Cy, Py = stats
+    mu, B, W = m["mu"], m["B"], m["W"]
+    ybar = y_acc / M
+    if update_mu:
+        mu = ybar
+    if update_B:
+        if update_mu:
+            iB = Py / M - np.outer(mu, mu)
+        else:
+            muybar = np.outer(mu, ybar)
+            iB = Py / M - muybar - muybar + np.outer(mu, mu)
+        B = inv_pdmat(iB)
+    if update_W:
+        iW = (S - Cy - Cy.T + Ry) / N
+        W = inv_pdmat(iW) if fullcov_W else np.diag(1 / np.diag(iW))
+    return {"type": "frplda", "mu": mu, "B": B, "W": W}
+
+
+def frplda_fit(D, m=None, epochs=20, ml_md="ml+md", md_epochs=None, **updates):
+    """The training loop of hyperion/pdfs/plda/plda_base.py:34-88 for the two-covariance model (its
+    minimum-divergence step does nothing, frplda.py:235-236): returns (model, elbo per epoch)."""
+    if m is None:
+        mu, B, W = frplda_initialize(D)
+        m = {"type": "frplda", "mu": mu, "B": B, "W": W}
+    elbo = np.zeros((epochs,))
+    for epoch in range(epochs):
+        stats = frplda_estep(m, D)
+        elbo[epoch] = frplda_elbo(m, stats)
+        if ml_md != "md":
+            m = frplda_mstep_ml(m, stats, **updates)
+    return m, elbo
+
+
+# ----------------------------------------------------------------------------- sampling, adaptation
+def plda_sample(m, num_classes, num_samples_per_class, seed=1024, return_y=False):
+    """Vectors drawn from a model with numpy's RandomState, in the reference's order of draws
+    (hyperion/pdfs/plda/splda.py:381-399, frplda.py:368-394, plda.py:541-562)."""
+    rng = np.random.RandomState(seed=seed)
+    mu = m["mu"]
+    d, n = mu.shape[0], num_classes * num_samples_per_class
+    if m["type"] == "frplda":
+        chol_Sb = chol_upper(inv_pdmat(m["B"]))
+        chol_Sw = chol_upper(inv_pdmat(m["W"]))
+        z = np.dot(rng.normal(size=(n, d)), chol_Sw)
+        y = np.dot(rng.normal(size=(num_classes, d)), chol_Sb) + mu
+        y = np.repeat(y, num_samples_per_class, axis=0)
+        return (y + z, y) if return_y else y + z
+    if m["type"] == "splda":
+        z = np.dot(rng.normal(size=(n, d)), chol_upper(inv_pdmat(m["W"])))
+        y = np.dot(rng.normal(size=(num_classes, m["V"].shape[0])), m["V"]) + mu
+        return np.repeat(y, num_samples_per_class, axis=0) + z
+    z1 = rng.normal(size=(n, d)) / m["D"]
+    z2 = np.dot(rng.normal(size=(n, m["U"].shape[0])), m["U"])
+    y = np.dot(rng.normal(size=(num_classes, m["V"].shape[0])), m["V"]) + mu
+    return np.repeat(y, num_samples_per_class, axis=0) + z1 + z2
+
+
+def plda_weighted_avg_model(m, other, w_mu, w_B, w_W, floor_iD=1e-5):
+    """Interpolation of a model towards another one, on covariances (hyperion/pdfs/plda/
+    plda_base.py:362-363, splda.py:401-419, frplda.py:396-410, plda.py:564-589): returns the new model."""
+    out = dict(m)
+    out["mu"] = w_mu * other["mu"] + (1 - w_mu) * m["mu"]
+    kind = m["type"]
+    if kind == "frplda":
+        if w_B > 0:
+            out["B"] = inv_pdmat(w_B * inv_pdmat(other["B"]) + (1 - w_B) * inv_pdmat(m["B"]))
+        if w_W > 0:
+            out["W"] = inv_pdmat(w_W * inv_pdmat(other["W"]) + (1 - w_W) * inv_pdmat(m["W"]))
+        return out
+    y_dim = m["V"].shape[0]
+    if w_B > 0:
+        Sb = w_B * np.dot(other["V"].T, other["V"]) + (1 - w_B) * np.dot(m["V"].T, m["V"])
+        w, V = sla.eigh(Sb)
+        out["V"] = (np.sqrt(w[-y_dim:]) * V[:, -y_dim:]).T
+    if w_W > 0 and kind == "splda":
+        out["W"] = inv_pdmat(w_W * inv_pdmat(other["W"]) + (1 - w_W) * inv_pdmat(m["W"]))
+    if w_W > 0 and kind == "plda":
+        z_dim = m["U"].shape[0]
+        Sw0 = np.dot(m["U"].T, m["U"]) + np.diag(1 / m["D"])
+        Sw = w_W * (np.dot(other["U"].T, other["U"]) + np.diag(1 / other["D"])) + (1 - w_W) * Sw0
+        w, U = sla.eigh(Sw)
+        U = (np.sqrt(w) * U)[:, -z_dim:].T
+        iD = np.diag(Sw - np.dot(U.T, U)).copy()
+        iD[iD < floor_iD] = floor_iD
+        out["U"], out["D"] = U, 1 / iD
+    return out
+
+
 def _largest_first_positive_top(V):
     V = np.fliplr(V)
     V[:, V[0, :] < 0] *= -1

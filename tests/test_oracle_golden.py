@@ -226,3 +226,56 @@ def test_torch_layer_formula_agrees_with_numpy_model(golden):
         self_scores = O.splda_torch_layer_llr(x1, None, m["mu"], m["V"], U)
         assert np.allclose(self_scores, O.llr_1vs1(m, x1, x1), rtol=1e-9, atol=1e-9)
         assert np.allclose(self_scores, self_scores.T, rtol=1e-12, atol=1e-12)
+
+
+_FRPLDA_SETUPS = {
+    "a": (False, dict(epochs=6, ml_md="ml+md"), {}, 0.0),
+    "b": (True, dict(epochs=4, ml_md="ml"), {}, 0.0),
+    "c": (False, dict(epochs=5, ml_md="ml"), dict(update_mu=False), 0.02),
+    "d": (False, dict(epochs=3, ml_md="ml"), dict(update_B=False, fullcov_W=False), 0.0),
+}
+
+
+def test_frplda_training_restatement(golden):
+    """FRPLDA EM, sampler and model interpolation of the oracle against the reference's results
+    (fixture made by oracle/gen_golden.py gen_frplda_training), including the set-up of the
+    reference's own test (tests/hyperion/pdfs/plda/test_frplda.py:22-29, 137-145)."""
+    g = golden("frplda_training")
+    truth = {"type": "frplda", "mu": g["t2_mu"], "B": g["t2_B"], "W": g["t2_W"]}
+    x2, y2 = O.plda_sample(truth, 50, 10, seed=1024, return_y=True)
+    assert np.allclose(x2, g["t2_x"], rtol=1e-12, atol=1e-12) and np.allclose(y2, g["t2_y"], rtol=1e-12, atol=1e-12)
+    m, elbo = O.frplda_fit(O.compute_stats_hard(g["t2_x"], np.repeat(np.arange(50), 10)))
+    assert np.allclose(elbo, g["t2_elbo"], rtol=1e-9)
+    for p in ("mu", "B", "W"):
+        assert np.allclose(m[p], g["t2_fit_" + p], rtol=1e-7, atol=1e-9), p
+
+    x, y, w = g["x"], g["y"], g["w"]
+    for tag, D in (("", O.compute_stats_hard(x, y)), ("w_", _weighted_stats(x, y, w))):
+        for a, name in zip(O.frplda_initialize(D), ("mu", "B", "W")):
+            assert np.allclose(a, g["init_" + tag + name], rtol=1e-9, atol=1e-11), name
+        m0 = {"type": "frplda", "mu": g["init_" + tag + "mu"], "B": g["init_" + tag + "B"], "W": g["init_" + tag + "W"]}
+        got = O.frplda_compute_py_g_x(m0, D, return_cov=True, return_logpy_0=True, return_acc=True)
+        for a, name in zip(got, ("y", "cov", "logpy", "Ry", "Py")):
+            assert np.allclose(a, g["post_" + tag + name], rtol=1e-9, atol=1e-11), name
+        assert np.isclose(O.frplda_elbo(m0, O.frplda_estep(m0, D)), g["elbo0_" + tag[:1]], rtol=1e-11)
+    for tag, (weighted, kw, upd, shift) in _FRPLDA_SETUPS.items():
+        D = _weighted_stats(x, y, w) if weighted else O.compute_stats_hard(x, y)
+        start = None
+        if shift:
+            mu0, B0, W0 = O.frplda_initialize(D)
+            start = {"type": "frplda", "mu": mu0 + shift, "B": B0, "W": W0}
+        m, elbo = O.frplda_fit(D, m=start, **kw, **upd)
+        assert np.allclose(elbo, g["fit_%s_elbo" % tag], rtol=1e-9)
+        for p in ("mu", "B", "W"):
+            assert np.allclose(m[p], g["fit_%s_%s" % (tag, p)], rtol=1e-7, atol=1e-9), (tag, p)
+
+    for kind, keys in (("splda", "mu V W"), ("frplda", "mu B W"), ("plda", "mu V U D")):
+        a = dict({k: g["adapt_%s_a_%s" % (kind, k)] for k in keys.split()}, type=kind)
+        b = dict({k: g["adapt_%s_b_%s" % (kind, k)] for k in keys.split()}, type=kind)
+        assert np.allclose(O.plda_sample(a, 4, 3, seed=11), g["sample_" + kind], rtol=1e-12, atol=1e-12)
+        out = O.plda_weighted_avg_model(a, b, 0.75, 0.5, 0.25)
+        for k in keys.split():
+            got, ref = out[k], g["adapt_%s_out_%s" % (kind, k)]
+            if k in ("V", "U"):  # eigenvector rows: defined up to sign
+                got, ref = got.T @ got, ref.T @ ref
+            assert np.allclose(got, ref, rtol=1e-9, atol=1e-11), (kind, k)
