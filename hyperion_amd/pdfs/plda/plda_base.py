@@ -291,6 +291,56 @@ class PLDABase(HypModel):
             self.initialize(D)
         return self._em_epochs(D, D_val, epochs, ml_md, md_epochs)
 
+    def _posterior(self, D, want_logpy):
+        """Device posterior means of the speaker factors of SPLDA and PLDA (`_WV()` gives W V^T and
+        V W V^T, through the Woodbury form for the full model).  V W V^T = Q diag(lam) Q^T makes
+        every L_i = I + N_i V W V^T diagonal in the basis Q, so the reference's loop over distinct
+        counts with a Cholesky each (splda.py:112-142, plda.py:157-186) is two products and one
+        scaling pass.  Returns (Z, y, logpy, logpy_sum, lam, Q): Z = [F | y] as one device buffer."""
+        from scipy import linalg as sla
+
+        torch = engine.require_gpu()
+        mu = np.asarray(self.mu, dtype=np.float64)
+        WV, VV = self._WV()
+        lam, Q = sla.eigh(0.5 * (VV + VV.T))
+        lam = np.maximum(lam, 0.0)
+        B = WV @ Q  # [d, K]
+        M, d = D.F.shape
+        K = VV.shape[0]
+        Z = torch.empty((M, d + K), dtype=torch.float64, device="cuda")
+        Z[:, :d] = D.F
+        T = engine.gemm64(D.F, np.ascontiguousarray(B.T), bias=-(mu @ B))  # (F - mu) W V^T Q
+        logpy, total = engine.splda_posterior(T, D.N, lam)
+        y = engine.gemm64(T, Q, out=Z[:, d:])  # back to the model's basis
+        return Z, y, (logpy if want_logpy else None), total, lam, Q
+
+    @staticmethod
+    def _posterior_cov_sums(N, lam, Q):
+        """sum_i L_i^-1 and sum_i N_i L_i^-1 (Py and Ry of splda.py:144-146) from the distinct counts."""
+        uniq, cnt = np.unique(N, return_counts=True)
+        inv = 1.0 / (1.0 + uniq[:, None] * lam[None, :])
+        Py = (Q * (cnt[:, None] * inv).sum(axis=0)) @ Q.T
+        Ry = (Q * ((cnt * uniq)[:, None] * inv).sum(axis=0)) @ Q.T
+        return Ry, Py
+
+    @engine.small_host_algebra
+    def compute_py_g_x(self, D, return_cov=False, return_logpy_0=False, return_acc=False):
+        """Posterior of the speaker factor of every class given its statistics (splda.py:73-158, plda.py:119-198):
+        y [M, y_dim] and on request the posterior covariances [M, y_dim, y_dim], the log
+        normalisers logpy [M], and the accumulators (Ry, Py).  Host arrays out."""
+        D = ClassStats.of(D)
+        _, y, logpy, _, lam, Q = self._posterior(D, return_logpy_0)
+        r = [y.cpu().numpy().astype(float_cpu())]
+        if return_cov:
+            uniq, inverse = np.unique(D.N, return_inverse=True)
+            cov = np.einsum("ak,uk,bk->uab", Q, 1.0 / (1.0 + uniq[:, None] * lam[None, :]), Q)
+            r.append(cov[inverse].astype(float_cpu()))
+        if return_logpy_0:
+            r.append(logpy.cpu().numpy().astype(float_cpu()))
+        if return_acc:
+            r += list(self._posterior_cov_sums(D.N, lam, Q))
+        return r[0] if len(r) == 1 else tuple(r)
+
     def _em_epochs(self, D, D_val, epochs, ml_md, md_epochs, after_epoch=None, also=None):
         """The epoch loop shared by fit and the adaptation variants."""
         use_ml = ml_md != "md"

@@ -532,6 +532,73 @@ def gen_frplda_training():
     print("frplda training ok")
 
 
+def gen_plda_training():
+    """EM training of the full PLDA model in the reference (hyperion/pdfs/plda/plda.py:91-394):
+    first model, posterior, E-step accumulators, ELBO sequences and trained parameters."""
+    rng = np.random.RandomState(79)
+    d, K, Z, ncls = 8, 3, 2, 40
+    counts = rng.randint(1, 7, ncls)
+    y = np.repeat(np.arange(ncls), counts)
+    n = y.shape[0]
+    x = (rng.randn(ncls, K)[y] @ rng.randn(K, d) + 0.8 * rng.randn(n, Z) @ rng.randn(Z, d)
+         + 0.5 * rng.randn(n, d) * np.exp(rng.uniform(-0.5, 0.5, d)) + 1.5)
+    perm = rng.permutation(n)
+    x, y = x[perm], y[perm]
+    w = rng.uniform(0.5, 2.0, n)
+    out = dict(x=x, y=y, w=w, y_dim=K, z_dim=Z)
+    D = R.PLDA.compute_stats_hard(x, y)
+    Dw = R.PLDA.compute_stats_hard(x, y, sample_weight=w)
+    names = ("N", "M", "F", "S", "logpy", "y_acc", "Ry1", "Ry", "Cy", "Py", "Rz1", "Rz", "Ryz", "Cz")
+    for tag, DD in (("", D), ("w_", Dw)):
+        r = R.PLDA(y_dim=K, z_dim=Z)
+        r.initialize(DD)
+        init = O.plda_initialize(DD, K, Z)
+        for a, b, k in zip(init, (r.mu, r.V, r.U, r.D), ("mu", "V", "U", "D")):
+            close(a, b, 1e-9)
+            out["init_" + tag + k] = b
+        m0 = {"type": "plda", "mu": r.mu.copy(), "V": r.V.copy(), "U": r.U.copy(), "D": r.D.copy()}
+        got = r.compute_py_g_x(DD, return_cov=True, return_logpy_0=True, return_acc=True)
+        for a, b in zip(O.plda_compute_py_g_x(m0, DD, return_cov=True, return_logpy_0=True, return_acc=True), got):
+            close(a, b)
+        for name, v in zip(("y", "cov", "logpy", "Ry", "Py"), got):
+            out["post_" + tag + name] = v
+        st = r.Estep(DD)
+        so = O.plda_estep(m0, DD)
+        for a, b, k in zip(so, st, names):
+            close(a, b, 1e-9)
+            out["estep_" + tag + k] = np.asarray(b)
+        out["elbo0_" + tag[:1]] = r.elbo(st)
+        close(O.plda_elbo(m0, so), r.elbo(st))
+
+    setups = {
+        "a": (D, dict(epochs=6, ml_md="ml+md"), {}),
+        "b": (Dw, dict(epochs=2, ml_md="ml"), {}),
+        "c": (D, dict(epochs=5, ml_md="ml+md", md_epochs=[1, 3]), dict(update_D=False)),
+        "d": (D, dict(epochs=3, ml_md="md"), {}),
+        "e": (D, dict(epochs=3, ml_md="ml"), dict(update_mu=False)),
+    }
+    for tag, (DD, kw, upd) in setups.items():
+        r = R.PLDA(y_dim=K, z_dim=Z, **upd)
+        if DD is D:
+            elbo, elbo_norm = r.fit(x, class_ids=y, **kw)
+        else:  # fit() does not pass sample weights on (plda_base.py:56): the same loop on weighted statistics
+            r.initialize(DD)
+            elbo = np.zeros(kw["epochs"])
+            for e in range(kw["epochs"]):
+                st = r.Estep(DD)
+                elbo[e] = r.elbo(st)
+                r.MstepML(st)
+            elbo_norm = elbo / np.sum(DD[0])
+        m, eo = O.plda_fit(DD, K, Z, **kw, **upd)
+        close(eo, elbo, 1e-9)
+        for k in ("mu", "V", "U", "D"):
+            close(m[k], getattr(r, k), 1e-7)
+            out["fit_%s_%s" % (tag, k)] = getattr(r, k)
+        out["fit_%s_elbo" % tag], out["fit_%s_elbo_norm" % tag] = elbo, elbo_norm
+    np.savez_compressed(os.path.join(OUT, "plda_training.npz"), **out)
+    print("plda training ok")
+
+
 def gen_diarization():
     """The diarization consumer of the reference (hyperion/diarization/diar_ahc_plda.py:122-168,
     hyperion/clustering/ahc.py:36-110): length normalisation, PCA fitted on the recording, projected
@@ -561,6 +628,7 @@ def gen_diarization():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gen_frplda_training()
+    gen_plda_training()
     gen_diarization()
     gen_splda_training()
     gen_training_stats()

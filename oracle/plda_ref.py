@@ -734,6 +734,205 @@ def frplda_fit(D, m=None, epochs=20, ml_md="ml+md", md_epochs=None, **updates):
     return m, elbo
 
 
+# ----------------------------------------------------------------------------- full PLDA training
+def plda_aux_all(V, U, D):
+    """Every auxiliary value of hyperion/pdfs/plda/plda.py:77-89: DU, J, the upper Cholesky factor of
+    Lz = I + (U D) U^T, log|Lz|, the within-class precision W, and the products VW, VWV."""
+    DV = V * D
+    DU = U * D
+    J = np.dot(V, DU.T)
+    Rz = chol_upper(np.eye(U.shape[0]) + np.dot(DU, U.T))
+    DUiLz = _cho_solve_right(Rz, DU.T)
+    W = np.diag(D) - np.dot(DUiLz, DU)
+    VW = DV.T - np.dot(DUiLz, J.T)
+    return {"DU": DU, "J": J, "Rz": Rz, "log_Lz": 2 * np.sum(np.log(np.diag(Rz))), "W": W, "VW": VW,
+            "VWV": np.dot(V, VW)}
+
+
+def plda_initialize(D, y_dim, z_dim, floor_iD=1e-5):
+    """hyperion/pdfs/plda/plda.py:91-117: V from the SVD of the centred class means, U from the
+    leading eigenvectors of the residual scatter, D from what those leave on the diagonal."""
+    N, F, S = D
+    Vytilde = F / N[:, None]
+    mu = np.mean(Vytilde, axis=0)
+    _, s, Vt = sla.svd(Vytilde - mu, full_matrices=False)
+    V = s[:y_dim, None] * Vt[:y_dim, :]
+    C = (S - np.dot((N[:, None] * Vytilde).T, Vytilde)) / np.sum(N)
+    w, E = sla.eigh(C)
+    U = np.fliplr(E * np.sqrt(w))[:, :z_dim].T
+    iD = np.diag(C - np.dot(U.T, U)).copy()
+    iD[iD < floor_iD] = floor_iD
+    return mu, V, U, 1 / iD
+
+
+def plda_compute_py_g_x(m, D, return_cov=False, return_logpy_0=False, return_acc=False):
+    """hyperion/pdfs/plda/plda.py:119-198: the SPLDA posterior with W V^T := _VW, V W V^T := _VWV."""
+    N, F, _ = D
+    aux = plda_aux_all(m["V"], m["U"], m["D"])
+    y_dim = m["V"].shape[0]
+    M = F.shape[0]
+    gamma = np.dot(F - m["mu"], aux["VW"])
+    whole = bool(np.all(np.ceil(N) == N))
+    compute_inv = return_cov or return_acc
+    y = np.zeros((M, y_dim))
+    Sigma_y = np.zeros((M, y_dim, y_dim)) if return_cov else None
+    logpy = -0.5 * y_dim * np.log(2 * np.pi) * np.ones((M,))
+    Py, Ry = np.zeros((y_dim, y_dim)), np.zeros((y_dim, y_dim))
+    for k in (np.unique(N) if whole else range(M)):
+        if whole:
+            i = (N == k).nonzero()[0]
+            N_i, M_i = k, len(i)
+        else:
+            i, N_i, M_i = k, N[k], 1
+        R = chol_upper(np.eye(y_dim) + N_i * aux["VWV"])
+        y[i, :] = _cho_solve_right(R, gamma[i, :])
+        if compute_inv:
+            iL = _cho_solve_right(R, np.eye(y_dim))
+        if return_cov:
+            Sigma_y[i, :, :] = iL
+        if return_logpy_0:
+            logpy[i] += 0.5 * (2 * np.sum(np.log(np.diag(R))) - np.sum(y[i, :] * gamma[i, :], axis=-1))
+        if return_acc:
+            Py += M_i * iL
+            Ry += N_i * M_i * iL
+    out = [y]
+    if return_cov:
+        out.append(Sigma_y)
+    if return_logpy_0:
+        out.append(logpy)
+    if return_acc:
+        out += [Ry, Py]
+    return out[0] if len(out) == 1 else tuple(out)
+
+
+def plda_estep(m, D):
+    """hyperion/pdfs/plda/plda.py:200-264.  The channel-factor accumulators (Rz1, Rz, Ryz, Cz) are
+    algebra on the speaker-factor ones.  In Cz the reference subtracts the INNER product of the
+    total first-order statistic and mu from every entry of S (np.dot of two vectors, plda.py:214);
+    the restatement does the same."""
+    N, F, S = D
+    mu = m["mu"]
+    aux = plda_aux_all(m["V"], m["U"], m["D"])
+    DU, J, Rz_chol = aux["DU"], aux["J"], aux["Rz"]
+    mult_iLz = lambda X: _cho_solve_right(Rz_chol, X)  # noqa: E731
+    y, logpy, Ry, Py = plda_compute_py_g_x(m, D, return_logpy_0=True, return_acc=True)
+    N_tot = np.sum(N)
+    F_tot = np.sum(F, axis=0)
+    y_acc = np.sum(y, axis=0)
+    Cy = np.dot(F.T, y)
+    A = np.dot(S - np.dot(F_tot.T, mu), DU.T) - np.dot(Cy, J)
+    Cz = mult_iLz(A)
+    Niy = y * N[:, None]
+    Ry1 = np.sum(Niy, axis=0)
+    Ry = Ry + np.dot(Niy.T, y)
+    Py = Py + np.dot(y.T, y)
+    Fc_acc = np.sum(F - np.outer(N, mu), axis=0)
+    Fmu = np.outer(F_tot, mu)
+    Sc = S - Fmu - Fmu.T + N_tot * np.outer(mu, mu)
+    Rz1 = mult_iLz(np.dot(Fc_acc, DU.T) - np.dot(Ry1, J))
+    Cbary = Cy - np.outer(mu, Ry1)
+    Ryz = mult_iLz(np.dot(Cbary.T, DU.T) - np.dot(Ry, J))
+    A = np.dot(np.dot(DU, Cbary), J)
+    B = np.dot(np.dot(DU, Sc), DU.T) - A - A.T + np.dot(np.dot(J.T, Ry), J)
+    B = mult_iLz(B)
+    Rz = mult_iLz(B.T).T + N_tot * mult_iLz(np.eye(DU.shape[0]))
+    return (N_tot, F.shape[0], F_tot, S, np.sum(logpy), y_acc, Ry1, Ry, Cy, Py, Rz1, Rz, Ryz, Cz)
+
+
+def plda_elbo(m, stats):
+    """hyperion/pdfs/plda/plda.py:266-282."""
+    N, M, F, S, logpy_x = stats[:5]
+    mu = m["mu"]
+    aux = plda_aux_all(m["V"], m["U"], m["D"])
+    Fmu = np.outer(F, mu)
+    Shat = S - Fmu - Fmu.T + N * np.outer(mu, mu)
+    logpx_y = 0.5 * (-N * mu.shape[0] * np.log(2 * np.pi) + N * (np.sum(np.log(m["D"])) - aux["log_Lz"])
+                     - np.inner(aux["W"].ravel(), Shat.ravel()))
+    return logpx_y - 0.5 * M * m["V"].shape[0] * np.log(2 * np.pi) - logpy_x
+
+
+def plda_mstep_ml(m, stats, update_mu=True, update_V=True, update_U=True, update_D=True, floor_iD=1e-5):
+    """hyperion/pdfs/plda/plda.py:284-362, branch by branch as written there (the partial-update
+    branches included, whatever they do); returns the updated model."""
+    N, M, F, S, _, y_acc, Ry1, Ry, Cy, Py, Rz1, Rz, Ryz, Cz = stats
+    mu, V, U, Dg = m["mu"], m["V"], m["U"], m["D"]
+    y_dim = V.shape[0]
+    solve = lambda A, C: sla.cho_solve((chol_upper(A), False), C)  # noqa: E731
+    if update_mu and not update_V and not update_U:
+        mu = (F - np.dot(Ry1, V) - np.dot(Rz1, U)) / N
+    if not update_mu and update_V and not update_U:
+        V = solve(Ry, Cy.T - np.outer(Ry1, mu) - np.dot(Ryz, U))
+    if not update_mu and not update_V and update_U:
+        U = solve(Rz, Cz.T - np.dot(Ryz.T, V) - np.outer(Rz1, mu))
+    if not update_mu and update_V and update_U:
+        Rytilde = np.vstack((np.hstack((Ry, Ryz)), np.hstack((Ryz.T, Rz))))
+        C = np.vstack((Cy.T - np.outer(Ry1, mu), Cz.T - np.outer(Rz1, mu)))
+        Vtilde = solve(Rytilde, C)
+        V, U = Vtilde[:y_dim], Vtilde[y_dim:]
+    if update_mu and not update_V and update_U:
+        Rytilde = np.vstack((np.hstack((Rz, Rz1[:, None])), np.hstack((Rz1, N))))
+        C = np.vstack((Cz.T - np.outer(Ryz, V), F[:, None] - np.outer(Ry1, V)))
+        Vtilde = solve(Rytilde, C)
+        U, mu = Vtilde[:-1], Vtilde[-1]
+    if not update_mu and update_V and not update_U:
+        Rytilde = np.vstack((np.hstack((Ry, Ry1[:, None])), np.hstack((Ry1, N))))
+        C = np.vstack((Cy.T - np.dot(Ryz, U), F[:, None] - np.dot(Rz1, U)))
+        Vtilde = solve(Rytilde, C)
+        V, U = Vtilde[:-1], Vtilde[-1]
+    Rytilde = np.vstack((np.hstack((Ry, Ryz, Ry1[:, None])), np.hstack((Ryz.T, Rz, Rz1[:, None])),
+                         np.hstack((Ry1, Rz1, N))))
+    Cytilde = np.hstack((Cy, Cz, F[:, None]))
+    if update_mu and update_V and update_U:
+        Vtilde = solve(Rytilde, Cytilde.T)
+        V, U, mu = Vtilde[:y_dim, :], Vtilde[y_dim:-1], Vtilde[-1]
+    if update_D:
+        Vtilde = np.vstack((V, U, mu))
+        CVt = np.dot(Cytilde, Vtilde)
+        iD = np.diag((S - CVt - CVt.T + np.dot(np.dot(Vtilde.T, Rytilde), Vtilde)) / N).copy()
+        iD[iD < floor_iD] = floor_iD
+        Dg = 1 / iD
+    return {"type": "plda", "mu": mu, "V": V, "U": U, "D": Dg}
+
+
+def plda_mstep_md(m, stats, update_mu=True, update_V=True, update_U=True):
+    """hyperion/pdfs/plda/plda.py:364-394; returns the updated model."""
+    N, M, F, S, _, y_acc, Ry1, Ry, Cy, Py, Rz1, Rz, Ryz, Cz = stats
+    mu, V, U = m["mu"], m["V"], m["U"]
+    mu_y = y_acc / M
+    chol_Cov_y = chol_upper(Py / M - np.outer(mu_y, mu_y))
+    R = Ry - np.outer(Ry1, Ry1) / N
+    H = _cho_solve_right(chol_upper(R), Ryz.T - np.outer(Rz1, Ry1) / N)
+    mu_z = (Rz1 - np.dot(Ry1, H.T)) / N
+    RzyH = np.dot(Ryz.T, H.T)
+    Cov_z = (Rz - RzyH - RzyH.T + np.dot(np.dot(H, Ry), H.T)) / N - np.outer(mu_z, mu_z)
+    chol_Cov_z = chol_upper(Cov_z)
+    if update_mu:
+        mu = mu + np.dot(mu_y, V + np.dot(H.T, U)) + np.dot(mu_z, U)
+    if update_V:
+        V = np.dot(chol_Cov_y, V + np.dot(H.T, U))
+    if update_U:
+        U = np.dot(chol_Cov_z, U)
+    return {"type": "plda", "mu": mu, "V": V, "U": U, "D": m["D"]}
+
+
+def plda_fit(D, y_dim, z_dim, m=None, epochs=20, ml_md="ml+md", md_epochs=None, floor_iD=1e-5, **updates):
+    """The training loop of hyperion/pdfs/plda/plda_base.py:34-88 for the full model: returns
+    (model, elbo per epoch)."""
+    if m is None:
+        mu, V, U, Dg = plda_initialize(D, y_dim, z_dim, floor_iD)
+        m = {"type": "plda", "mu": mu, "V": V, "U": U, "D": Dg}
+    elbo = np.zeros((epochs,))
+    md_kw = {k: v for k, v in updates.items() if k in ("update_mu", "update_V", "update_U")}
+    for epoch in range(epochs):
+        stats = plda_estep(m, D)
+        elbo[epoch] = plda_elbo(m, stats)
+        if ml_md != "md":
+            m = plda_mstep_ml(m, stats, floor_iD=floor_iD, **updates)
+        if ml_md != "ml" and (md_epochs is None or epoch in md_epochs):
+            m = plda_mstep_md(m, stats, **md_kw)
+    return m, elbo
+
+
 # ----------------------------------------------------------------------------- sampling, adaptation
 def plda_sample(m, num_classes, num_samples_per_class, seed=1024, return_y=False):
     """Vectors drawn from a model with numpy's RandomState, in the reference's order of draws

@@ -279,3 +279,39 @@ def test_frplda_training_restatement(golden):
             if k in ("V", "U"):  # eigenvector rows: defined up to sign
                 got, ref = got.T @ got, ref.T @ ref
             assert np.allclose(got, ref, rtol=1e-9, atol=1e-11), (kind, k)
+
+
+_PLDA_SETUPS = {
+    "a": (False, dict(epochs=6, ml_md="ml+md"), {}),
+    "b": (True, dict(epochs=2, ml_md="ml"), {}),
+    "c": (False, dict(epochs=5, ml_md="ml+md", md_epochs=[1, 3]), dict(update_D=False)),
+    "d": (False, dict(epochs=3, ml_md="md"), {}),
+    "e": (False, dict(epochs=3, ml_md="ml"), dict(update_mu=False)),
+}
+_PLDA_STATS = ("N", "M", "F", "S", "logpy", "y_acc", "Ry1", "Ry", "Cy", "Py", "Rz1", "Rz", "Ryz", "Cz")
+
+
+def test_plda_training_restatement(golden):
+    """EM of the full PLDA model in the oracle against the reference's first model, posterior,
+    E-step accumulators, ELBO sequences and trained parameters (oracle/gen_golden.py gen_plda_training)."""
+    g = golden("plda_training")
+    x, y, w = g["x"], g["y"], g["w"]
+    K, Z = int(g["y_dim"]), int(g["z_dim"])
+    for tag, D in (("", O.compute_stats_hard(x, y)), ("w_", _weighted_stats(x, y, w))):
+        for a, name in zip(O.plda_initialize(D, K, Z), ("mu", "V", "U", "D")):
+            assert np.allclose(a, g["init_" + tag + name], rtol=1e-8, atol=1e-10), name
+        m0 = dict({k: g["init_" + tag + k] for k in ("mu", "V", "U", "D")}, type="plda")
+        got = O.plda_compute_py_g_x(m0, D, return_cov=True, return_logpy_0=True, return_acc=True)
+        for a, name in zip(got, ("y", "cov", "logpy", "Ry", "Py")):
+            assert np.allclose(a, g["post_" + tag + name], rtol=1e-9, atol=1e-11), name
+        st = O.plda_estep(m0, D)
+        for a, name in zip(st, _PLDA_STATS):
+            ref = g["estep_" + tag + name]
+            assert np.allclose(a, ref, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(ref).max())), name
+        assert np.isclose(O.plda_elbo(m0, st), g["elbo0_" + tag[:1]], rtol=1e-11)
+    for tag, (weighted, kw, upd) in _PLDA_SETUPS.items():
+        D = _weighted_stats(x, y, w) if weighted else O.compute_stats_hard(x, y)
+        m, elbo = O.plda_fit(D, K, Z, **kw, **upd)
+        assert np.allclose(elbo, g["fit_%s_elbo" % tag], rtol=1e-9)
+        for p in ("mu", "V", "U", "D"):
+            assert np.allclose(m[p], g["fit_%s_%s" % (tag, p)], rtol=1e-6, atol=1e-8), (tag, p)
