@@ -249,6 +249,35 @@ def gen_metrics():
     close(O.compute_eer(tar, non), out["eer"])
     close(O.compute_min_dcf(tar, non, 0.05)[0], out["min_dcf_005"])
     close(O.compute_min_dcf(tar, non, 0.01)[0], out["min_dcf_001"])
+    # the rest of the detection metrics (hyperion/metrics/dcf.py, eer.py), with ties and priors that
+    # put a threshold exactly on a score
+    from hyperion.metrics.dcf import compute_act_dcf, compute_dcf, fast_eval_dcf_eer
+    from hyperion.metrics.eer import compute_prbep
+    from hyperion.metrics.roc import compute_rocch
+    tq, nq = np.round(tar, 1), np.round(non, 1)  # many ties, within and across the classes
+    priors = np.array([0.001, 0.01, 0.05, 0.5, 1 / (1 + np.exp(tq[7]))])
+    priors.sort()
+    for tag, (a, b) in (("", (tar, non)), ("q_", (tq, nq))):
+        pm, pf = compute_rocch(a, b)
+        close(O.compute_rocch(a, b)[0], pm), close(O.compute_rocch(a, b)[1], pf)
+        mind = R.compute_min_dcf(a, b, priors)
+        actd = compute_act_dcf(a, b, priors)
+        act1 = compute_act_dcf(a, b, 0.05, normalize=False)
+        fast = fast_eval_dcf_eer(a, b, priors)
+        for x, y in zip(O.compute_min_dcf_multi(a, b, priors), mind):
+            close(x, y)
+        for x, y in zip(O.compute_act_dcf(a, b, priors), actd):
+            close(x, y)
+        for x, y in zip(O.compute_act_dcf(a, b, 0.05, normalize=False), act1):
+            close(x, y)
+        for x, y in zip(O.fast_eval_dcf_eer(a, b, priors), fast):
+            close(x, y)
+        close(O.compute_prbep(a, b), compute_prbep(a, b))
+        close(O.compute_dcf(pm, pf, priors, False), compute_dcf(pm, pf, priors, False))
+        out.update({tag + "rocch_pmiss": pm, tag + "rocch_pfa": pf, tag + "prbep": compute_prbep(a, b),
+                    tag + "min_dcf": np.stack(mind), tag + "act_dcf": np.stack(actd), tag + "act_dcf_005_raw": np.array([float(np.ravel(v)[0]) for v in act1]),
+                    tag + "fast_min": fast[0], tag + "fast_act": fast[1], tag + "fast_eer": fast[2], tag + "fast_prbep": fast[3]})
+    out.update(priors=priors, tar_q=tq, non_q=nq)
     # math helpers (tests/hyperion/utils/test_math.py pins them against scipy inv/det)
     A = rng.randn(9, 9)
     A = A @ A.T + np.eye(9)

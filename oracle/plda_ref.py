@@ -1105,3 +1105,68 @@ def compute_min_dcf(tar, non, prior, normalize=True):
         dcf = dcf / min(prior, 1 - prior)
     i = int(np.argmin(dcf))
     return dcf[i], p_miss[i], p_fa[i]
+
+
+def compute_dcf(p_miss, p_fa, prior, normalize=True):
+    """hyperion/metrics/dcf.py:11-33: [len(prior), len(p_miss)] (or [len(p_miss)] for one prior)."""
+    prior = np.asarray(prior)
+    if prior.ndim == 1:
+        prior = prior[:, None]
+    dcf = prior * p_miss + (1 - prior) * p_fa
+    if normalize:
+        dcf = dcf / np.minimum(prior, 1 - prior)
+    return dcf
+
+
+def compute_min_dcf_multi(tar, non, prior, normalize=True):
+    """hyperion/metrics/dcf.py:36-65 for a prior or an ascending vector of priors:
+    (min DCF, P_miss there, P_fa there)."""
+    p_miss, p_fa = compute_rocch(tar, non)
+    dcf = compute_dcf(p_miss, p_fa, prior, normalize)
+    idx = np.argmin(dcf, axis=-1)
+    if dcf.ndim == 1:
+        return dcf[idx], p_miss[idx], p_fa[idx]
+    return dcf[np.arange(dcf.shape[0]), idx], p_miss[idx], p_fa[idx]
+
+
+def compute_act_dcf(tar, non, prior, normalize=True):
+    """hyperion/metrics/dcf.py:68-136: detection cost at the Bayes thresholds log((1 - p) / p) of
+    scores taken as log-likelihood ratios; ranks from stable sorts of [thresholds, scores]."""
+    prior = np.asarray(prior)
+    if prior.ndim == 1:
+        assert np.all(prior == np.sort(prior, kind="mergesort")), "priors must be in ascending order"
+    else:
+        prior = prior[None]
+    num_priors = len(prior)
+    ntar, nnon = len(tar), len(non)
+    t = -np.log(prior) + np.log(1 - prior)
+    ii = np.argsort(np.concatenate((t, tar)), kind="mergesort")
+    r = np.zeros((num_priors + ntar), dtype="int32")
+    r[ii] = np.arange(1, num_priors + ntar + 1)
+    n_miss = r[:num_priors] - np.arange(num_priors, 0, -1)
+    ii = np.argsort(np.concatenate((t, non)), kind="mergesort")
+    r = np.zeros((num_priors + nnon), dtype="int32")
+    r[ii] = np.arange(1, num_priors + nnon + 1)
+    n_fa = nnon - r[:num_priors] + np.arange(num_priors, 0, -1)
+    p_miss = n_miss / ntar
+    p_fa = n_fa / nnon
+    act_dcf = prior * p_miss + (1 - prior) * p_fa
+    if normalize:
+        act_dcf = act_dcf / np.minimum(prior, 1 - prior)
+    if len(act_dcf) == 1:
+        act_dcf = act_dcf[0]
+    return act_dcf, p_miss, p_fa
+
+
+def compute_prbep(tar, non):
+    """hyperion/metrics/eer.py:25-39: the point of the hull where #misses = #false alarms."""
+    p_miss, p_fa = compute_rocch(tar, non)
+    return rocch2eer(p_miss * len(tar), p_fa * len(non))
+
+
+def fast_eval_dcf_eer(tar, non, prior, normalize_dcf=True):
+    """hyperion/metrics/dcf.py:139-175: (min DCF, actual DCF, EER, PRBEP) from one hull."""
+    p_miss, p_fa = compute_rocch(tar, non)
+    dcf = compute_dcf(p_miss, p_fa, prior, normalize_dcf)
+    return (np.min(dcf, axis=-1), compute_act_dcf(tar, non, prior, normalize_dcf)[0], rocch2eer(p_miss, p_fa),
+            rocch2eer(p_miss * len(tar), p_fa * len(non)))

@@ -315,3 +315,22 @@ def test_plda_training_restatement(golden):
         assert np.allclose(elbo, g["fit_%s_elbo" % tag], rtol=1e-9)
         for p in ("mu", "V", "U", "D"):
             assert np.allclose(m[p], g["fit_%s_%s" % (tag, p)], rtol=1e-6, atol=1e-8), (tag, p)
+
+
+@pytest.mark.parametrize("tag", ["", "q_"])
+def test_detection_metric_restatements(golden, tag):
+    """Hull, minimum / actual DCF over several priors, PRBEP and the combined evaluation of the oracle
+    against the reference's values, on continuous scores and on scores with many ties."""
+    g = golden("metrics_math")
+    tar, non = (g["tar"], g["non"]) if tag == "" else (g["tar_q"], g["non_q"])
+    priors = g["priors"]
+    pm, pf = O.compute_rocch(tar, non)
+    assert np.allclose(pm, g[tag + "rocch_pmiss"], rtol=0, atol=1e-13) and np.allclose(pf, g[tag + "rocch_pfa"], rtol=0, atol=1e-13)
+    assert np.allclose(np.stack(O.compute_min_dcf_multi(tar, non, priors)), g[tag + "min_dcf"], rtol=1e-12)
+    assert np.allclose(np.stack(O.compute_act_dcf(tar, non, priors)), g[tag + "act_dcf"], rtol=1e-12)
+    one = O.compute_act_dcf(tar, non, 0.05, normalize=False)
+    assert np.allclose([float(np.ravel(v)[0]) for v in one], g[tag + "act_dcf_005_raw"], rtol=1e-12)
+    assert np.isclose(O.compute_prbep(tar, non), g[tag + "prbep"], rtol=1e-12)
+    mn, act, eer, prbep = O.fast_eval_dcf_eer(tar, non, priors)
+    assert np.allclose(mn, g[tag + "fast_min"], rtol=1e-12) and np.allclose(act, g[tag + "fast_act"], rtol=1e-12)
+    assert np.isclose(eer, g[tag + "fast_eer"], rtol=1e-12) and np.isclose(prbep, g[tag + "fast_prbep"], rtol=1e-12)
