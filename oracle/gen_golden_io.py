@@ -43,6 +43,59 @@ def load_reference_io():
     return types.SimpleNamespace(**locals())
 
 
+def gen_vcr():
+    """Adds the labelled-vector loader's fixtures to tests/golden/trials/ without touching the others:
+    a `key class` list over the vectors of vectors.scp with classes of 1 to 9 vectors, and what the
+    reference's VectorClassReader returns for it under every pruning / splitting option."""
+    R = load_reference_io()
+    from hyperion.helpers.vector_class_reader import VectorClassReader
+
+    os.chdir(OUT)
+    with open("vectors.scp") as f:
+        keys = sorted(line.split()[0] for line in f)
+    rng = np.random.RandomState(5)
+    sizes = [9, 8, 7, 6, 5, 4, 3, 2, 1]
+    assert sum(sizes) <= len(keys)
+    order = rng.permutation(len(keys))[:sum(sizes)]
+    cls = np.repeat(["spk%d" % i for i in range(len(sizes))], sizes)
+    cls = cls[rng.permutation(len(cls))]
+    with open("train.utt2spk", "w") as f:
+        for i, c in zip(order, cls):
+            f.write("%s %s\n" % (keys[i], c))
+    with open("train.class2int", "w") as f:
+        for i in range(len(sizes)):
+            f.write("spk%d %d\n" % (i, len(sizes) - 1 - i))
+    cases = {
+        "plain": dict(),
+        "min3": dict(min_spc=3),
+        "max4_random": dict(min_spc=2, max_spc=4, spc_pruning_mode="random", vcr_seed=7),
+        "max4_last": dict(max_spc=4, spc_pruning_mode="last"),
+        "max4_first": dict(max_spc=4, spc_pruning_mode="first"),
+        "split3_seq": dict(csplit_max_spc=3, csplit_mode="sequential", csplit_min_spc=2),
+        "split4_seq_ov1": dict(csplit_max_spc=4, csplit_mode="sequential", csplit_overlap=1),
+        "split3_random": dict(csplit_max_spc=3, csplit_mode="random", vcr_seed=11),
+        "split_1part": dict(csplit_max_spc=3, csplit_mode="random_1part", csplit_min_spc=2, vcr_seed=3),
+        "class2int": dict(class2int_file="train.class2int", min_spc=2),
+        "twice": dict(csplit_max_spc=3, csplit_mode="random", csplit_once=False, vcr_seed=5),
+    }
+    out = {}
+    for name, kw in cases.items():
+        v = VectorClassReader("scp:vectors.scp", "train.utt2spk", **kw)
+        x, ids = v.read()
+        out[name + "_x"], out[name + "_ids"] = x, ids
+        out[name + "_keys"] = np.asarray(v.u2c.key, dtype=str)
+        out[name + "_spc"] = np.asarray(v.samples_per_class)
+        out[name + "_names"] = np.asarray(v.class_names, dtype=str)
+        if name == "twice":  # a new split on every read
+            x2, ids2 = v.read()
+            out[name + "_x2"], out[name + "_ids2"] = x2, ids2
+        if name == "min3":
+            x3, w3 = v.read(return_3d=True)
+            out[name + "_x3d"], out[name + "_w3d"] = x3, w3
+    np.savez_compressed("expected_vcr.npz", **out)
+    print("vcr fixtures ok:", {k: out[k + "_x"].shape[0] for k in cases})
+
+
 def main():
     R = load_reference_io()
     os.makedirs(OUT, exist_ok=True)
@@ -144,5 +197,7 @@ def main():
     print("wrote", OUT, sorted(os.listdir(OUT)))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "vcr":
+    gen_vcr()
+elif __name__ == "__main__":
     main()

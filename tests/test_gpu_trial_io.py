@@ -88,3 +88,35 @@ def test_job_grid_parts_tile_the_full_matrix(exp):
             cols.append(blk)
         rows.append(np.hstack(cols))
     assert np.allclose(np.vstack(rows), full, rtol=0, atol=2e-5 * np.abs(full).max())
+
+
+def test_training_recipe_flow(exp, tmp_path):
+    """The flow of a back-end training recipe (egs/voxceleb/v1/steps_be/train-be-v1.py:60-110):
+    labelled vectors through VectorClassReader with a pre-processing chain, LDA and SPLDA fitted on
+    them, both saved, loaded again, and the loaded pair scores like the fitted one."""
+    from hyperion_amd.helpers import PLDAFactory, VectorClassReader
+    from hyperion_amd.transforms import LDA, LNorm, TransformList
+
+    m, chain = _model_and_chain()
+    _, tl = _objects(m, chain)
+    g = np.load("expected_vcr.npz")
+    x, ids = VectorClassReader("scp:vectors.scp", "train.utt2spk", preproc=tl, min_spc=3).read()
+    assert np.array_equal(ids, g["min3_ids"])
+    assert np.allclose(x, O.chain_predict(g["min3_x"].astype(float), chain), rtol=1e-4, atol=1e-5)
+    raw, _ = VectorClassReader("scp:vectors.scp", "train.utt2spk", min_spc=3).read()
+    lda = LDA(lda_dim=6, name="lda")
+    lda.fit(raw, ids)
+    lnorm = LNorm(name="lnorm")
+    pre = TransformList([lda, lnorm])
+    y = pre.predict(raw)
+    plda = PLDAFactory.create_plda("splda", y_dim=3, name="plda")
+    elbo, _ = plda.fit(y, ids, epochs=5)
+    assert np.all(np.diff(elbo) > -1e-6 * abs(elbo[0]))
+    pre.save(str(tmp_path / "lda_lnorm.h5"))
+    plda.save(str(tmp_path / "plda.h5"))
+    pre2 = TransformList.load(str(tmp_path / "lda_lnorm.h5"))
+    plda2 = PLDAFactory.load_plda("splda", str(tmp_path / "plda.h5"))
+    s1 = plda.llr_1vs1(y[:10], y[10:])
+    s2 = plda2.llr_1vs1(pre2.predict(raw)[:10], pre2.predict(raw)[10:])
+    # the files hold float32 parameters
+    assert np.allclose(s1, s2, rtol=1e-3, atol=1e-3)
