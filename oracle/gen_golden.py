@@ -650,6 +650,24 @@ def gen_diarization():
         assert np.array_equal(got[0], ids)
         close(got[1], diar._ahc.Z, 1e-9)
         print("diarization", tag, "clusters:", len(np.unique(ids)))
+    # unsupervised calibration of the self-scores (diar_ahc_plda.py:100-120): a recording of three
+    # speakers and one of a single speaker, for which the BIC says "one Gaussian"
+    one = m["mu"] + (2.0 * rng.randn(4)) @ m["V"] + rng.multivariate_normal(np.zeros(12), np.linalg.inv(m["W"]), 6)
+    out["x_one"] = one
+    for tag, xx in (("three", x), ("one", one)):
+        xl = O.lnorm_predict(xx)
+        scores = model.llr_1vs1(xl, xl)
+        scores_cal, bic, gmm = DiarAHCPLDA._unsup_gmm_calibration(scores.copy())
+        scale, bias, bic_o, pi, mu, lam = O.unsup_gmm_calibration(scores)
+        close(bic_o, bic, 1e-9), close(pi, gmm.pi, 1e-9), close(mu, gmm.mu.ravel(), 1e-9), close(np.atleast_1d(lam), gmm.Lambda.ravel(), 1e-9)
+        close(scale * scores + bias, scores_cal, 1e-9)
+        out["cal_%s_bic" % tag], out["cal_%s_pi" % tag] = bic, gmm.pi
+        out["cal_%s_mu" % tag], out["cal_%s_Lambda" % tag] = gmm.mu.ravel(), gmm.Lambda.ravel()
+        diar = DiarAHCPLDA(ref_model(m), preproc=R.LNorm(), threshold=4.0, do_unsup_cal=True, use_bic=True)
+        ids = diar.cluster(xx.copy())
+        out["ids_bic_" + tag] = ids
+        assert np.array_equal(O.diar_ahc_plda_cluster(m, xx, 4.0, 1, use_bic=True)[0], ids)
+        print("unsup cal", tag, "bic", bic, "clusters", len(np.unique(ids)))
     np.savez_compressed(os.path.join(OUT, "diarization.npz"), **out)
     print("diarization ok")
 

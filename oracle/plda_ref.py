@@ -466,17 +466,63 @@ def ahc_flat_clusters_n(Z, num_clusters):
     return np.unique(flat, return_inverse=True)[1]
 
 
-def diar_ahc_plda_cluster(m, x, threshold=0.0, pca_var_r=1):
+def diar_ahc_plda_cluster(m, x, threshold=0.0, pca_var_r=1, use_bic=False):
     """hyperion/diarization/diar_ahc_plda.py:122-168 with a parameter-free LNorm as the
-    pre-processor and without the optional score calibration: (cluster ids, linkage)."""
+    pre-processor: (cluster ids, linkage).  use_bic: the unsupervised calibration is run and a
+    negative BIC (one Gaussian explains the scores) puts every segment in one cluster; the
+    calibrated scores themselves reach the clustering only together with a histogram plot there
+    (diar_ahc_plda.py:151-154), which is not restated."""
     x = lnorm_predict(x)
     mu, V, W = m["mu"], m["V"], m["W"]
     if pca_var_r < 1:
         pmu, T = pca_fit(x, pca_var_r=pca_var_r, whiten=True)
         x = lnorm_predict(np.dot(x - pmu, T))
         mu, V, W = splda_project(mu, V, W, T, pmu)
-    Z = ahc_fit(splda_llr_1vs1(x, x, mu, V, W))
+    scores = splda_llr_1vs1(x, x, mu, V, W)
+    if use_bic and unsup_gmm_calibration(scores)[2] < 0:
+        return np.zeros(len(x), dtype=int), None
+    Z = ahc_fit(scores)
     return ahc_flat_clusters(Z, threshold), Z
+
+
+def unsup_gmm_calibration(scores, var_floor=1e-3):
+    """hyperion/diarization/diar_ahc_plda.py:100-120 on the scores above the diagonal, with the
+    tied-variance Gaussian mixture of hyperion/pdfs/mixtures/gmm_tied_diag_cov.py restated for one
+    dimension: one Gaussian from the moments of the scores (:53-58; one EM epoch changes nothing);
+    its split into two at mean +- one deviation with the same precision (split_comp, :105-121); 20
+    EM epochs in which the component variances are floored at var_floor times their mean and then
+    pooled into the one shared variance (Mstep, :77-103).  The two Gaussians sharing a variance is
+    what makes the log-likelihood ratio of "same speaker" against "different speakers" a linear map
+    scale * s + bias of the score.  Returns (scale, bias, bic, pi [2], mu [2], Lambda)."""
+    n_all = scores.shape[0]
+    x = scores[np.triu(np.ones((n_all, n_all), dtype=bool), 1)]
+    n = len(x)
+    m1, lam1 = np.mean(x), 1.0 / np.std(x) ** 2
+
+    def comp_llk(pi, mu, lam):
+        return np.log(pi) + 0.5 * np.log(lam) - 0.5 * np.log(2 * np.pi) - 0.5 * lam * (x[:, None] - mu) ** 2
+
+    def log_prob(pi, mu, lam):
+        r = comp_llk(pi, mu, lam)
+        mx = np.max(r, axis=-1, keepdims=True)
+        return np.log(np.sum(np.exp(r - mx), axis=-1) + 1e-20) + mx[:, 0]
+
+    sd = 1.0 / np.sqrt(lam1)
+    pi, mu, lam = np.array([0.5, 0.5]), np.array([m1 + sd, m1 - sd]), lam1
+    for _ in range(20):
+        r = comp_llk(pi, mu, lam)
+        z = np.exp(r - np.max(r, axis=-1, keepdims=True))
+        z /= np.sum(z, axis=-1, keepdims=True)
+        N = np.sum(z, axis=0)
+        mu = np.dot(z.T, x) / N
+        S = np.dot(z.T, x * x) / N - mu * mu
+        S = np.maximum(S, var_floor * np.mean(S))
+        lam = 1.0 / (np.sum(N * S) / np.sum(N))
+        pi = N / np.sum(N)
+    scale = (mu[0] - mu[1]) * lam
+    bias = (mu[1] ** 2 - mu[0] ** 2) * lam / 2 + np.log(pi[0]) - np.log(pi[1])
+    bic = np.mean(log_prob(pi, mu, lam) - log_prob(np.array([1.0]), np.array([m1]), lam1)) - 4 * np.log(n) / 2 / n
+    return scale, bias, bic, pi, mu, lam
 
 
 # ----------------------------------------------------------------------------- SPLDA training

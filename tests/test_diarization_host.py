@@ -58,3 +58,17 @@ def test_ahc_mask_and_other_metrics():
     free = AHC()
     free.fit(-dist)
     assert free.get_flat_clusters(2, criterion="num_clusters")[0] == free.get_flat_clusters(2, criterion="num_clusters")[1]
+
+
+def test_oracle_restates_the_unsupervised_calibration(golden):
+    """Mixture, BIC and the BIC decision of the oracle against the reference's
+    (hyperion/diarization/diar_ahc_plda.py:100-120, gmm_tied_diag_cov.py)."""
+    g = golden("diarization")
+    m = {"mu": g["m_mu"], "V": g["m_V"], "W": g["m_W"]}
+    for tag, key in (("three", "x"), ("one", "x_one")):
+        xl = O.lnorm_predict(g[key])
+        scale, bias, bic, pi, mu, lam = O.unsup_gmm_calibration(O.splda_llr_1vs1(xl, xl, m["mu"], m["V"], m["W"]))
+        assert np.isclose(bic, g["cal_%s_bic" % tag], rtol=1e-9)
+        assert np.allclose(pi, g["cal_%s_pi" % tag], rtol=1e-9) and np.allclose(mu, g["cal_%s_mu" % tag], rtol=1e-9)
+        assert np.isclose(lam, g["cal_%s_Lambda" % tag][0], rtol=1e-9)
+        assert np.array_equal(O.diar_ahc_plda_cluster(m, g[key], 4.0, 1, use_bic=True)[0], g["ids_bic_" + tag])
