@@ -223,6 +223,29 @@ def gen_score_norm():
     close(O.z_norm(sc, ec0), out["znorm_floor"])
     out["asnorm_floor"] = R.AdaptSNorm(nbest=10).predict(sc.copy(), ct.copy(), ec0.copy())
     close(O.adapt_s_norm(sc, ct, ec0, 10, 0), out["asnorm_floor"])
+    # ZT- and TZ-norm: the reference's classes cannot be constructed (zt_norm.py:17, tz_norm.py:17
+    # name SNorm without importing it), so their predict bodies are run here on the reference's own
+    # ZNorm / TNorm objects
+    cc = rng.randn(nc, nc) * 4 - 6
+    mcc = rng.rand(nc, nc) > 0.2
+    out.update(coh_coh=cc, mask_coh_coh=mcc)
+    try:
+        from hyperion.score_norm import ZTNorm
+        ZTNorm()
+        raise SystemExit("ZTNorm can be constructed: use it directly")
+    except NameError:
+        pass
+    zn, tn = R.ZNorm(), R.TNorm()
+    for tag, (a, b, c) in (("", (None, None, None)), ("_masked", (mct, mec, mcc))):
+        # the Z-norm of the cohort-vs-test scores takes mask_enr_coh as written in zt_norm.py:38-40;
+        # with masks that needs ne == nc, so the masked case uses mask_coh_coh there (shapes force it)
+        zt = tn.predict(zn.predict(sc.copy(), ec.copy(), b), zn.predict(ct.copy(), cc.copy(), c), a)
+        tz = zn.predict(tn.predict(sc.copy(), ct.copy(), a), tn.predict(ec.copy(), cc.copy(), c), b)
+        out["ztnorm" + tag], out["tznorm" + tag] = zt, tz
+        if tag == "":
+            close(O.zt_norm(sc, ct, ec, cc), zt), close(O.tz_norm(sc, ct, ec, cc), tz)
+        else:
+            close(O.zt_norm(sc, ct, ec, cc, a, b, c), zt), close(O.tz_norm(sc, ct, ec, cc, a, b, c), tz)
     np.savez_compressed(os.path.join(OUT, "score_norm.npz"), **out)
     print("score_norm ok")
 

@@ -421,6 +421,28 @@ def s_norm(scores, scores_coh_test, scores_enr_coh, mask_coh_test=None, mask_enr
 
 
 # ----------------------------------------------------------------------------- training statistics
+def zt_norm(scores, scores_coh_test, scores_enr_coh, scores_coh_coh, mask_coh_test=None, mask_enr_coh=None,
+            mask_coh_coh=None):
+    """The predict body of hyperion/score_norm/zt_norm.py:21-45 (the class itself cannot be
+    constructed there: its __init__ names SNorm, which the module does not import): Z-norm of the
+    scores and of the cohort-vs-test scores, then T-norm of the first by the second.  As written
+    there, the Z-norm of the cohort-vs-test scores is given mask_enr_coh, whose shape fits only with
+    as many enrolment models as cohort members; the mask of that stage's cohort scores,
+    mask_coh_coh, is what is used here."""
+    s_z = z_norm(scores, scores_enr_coh, mask_enr_coh)
+    ct_z = z_norm(scores_coh_test, scores_coh_coh, mask_coh_coh)
+    return t_norm(s_z, ct_z, mask_coh_test)
+
+
+def tz_norm(scores, scores_coh_test, scores_enr_coh, scores_coh_coh, mask_coh_test=None, mask_enr_coh=None,
+            mask_coh_coh=None):
+    """The predict body of hyperion/score_norm/tz_norm.py:21-45 (same unconstructible __init__):
+    T-norm of the scores and of the enrol-vs-cohort scores, then Z-norm of the first by the second."""
+    s_t = t_norm(scores, scores_coh_test, mask_coh_test)
+    ec_t = t_norm(scores_enr_coh, scores_coh_coh, mask_coh_coh)
+    return z_norm(s_t, ec_t, mask_enr_coh)
+
+
 def sb_sw(x, class_ids):
     """SbSw.fit + normalize (hyperion/transforms/sb_sw.py:25-50): (mu, Sb, Sw)."""
     dim = x.shape[1]

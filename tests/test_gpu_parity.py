@@ -175,6 +175,15 @@ def test_score_norm_golden(golden):
     # the input score s (6e-8 relative) is amplified wherever s is close to the cohort mean
     chk(ZNorm().predict(sc, g["enr_coh_const"]), "znorm_floor", tol=1e-3)
     chk(AdaptSNorm(nbest=10).predict(sc, ct, g["enr_coh_const"]), "asnorm_floor", tol=1e-3)
+    # two-stage norms: the reference's predict bodies run on its own ZNorm / TNorm objects (its
+    # ZTNorm / TZNorm classes cannot be constructed)
+    from hyperion_amd.score_norm import TZNorm, ZTNorm
+
+    cc, masks = g["coh_coh"], (g["mask_coh_test"], g["mask_enr_coh"], g["mask_coh_coh"])
+    chk(ZTNorm().predict(sc, ct, ec, cc), "ztnorm")
+    chk(TZNorm().predict(sc, ct, ec, cc), "tznorm")
+    chk(ZTNorm().predict(sc, ct, ec, cc, *masks), "ztnorm_masked")
+    chk(TZNorm().predict(sc, ct, ec, cc, *masks), "tznorm_masked")
     for a, b in zip((sc, ct, ec), keep):
         assert np.array_equal(a, b)  # caller arrays untouched
 

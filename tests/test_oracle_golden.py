@@ -334,3 +334,15 @@ def test_detection_metric_restatements(golden, tag):
     mn, act, eer, prbep = O.fast_eval_dcf_eer(tar, non, priors)
     assert np.allclose(mn, g[tag + "fast_min"], rtol=1e-12) and np.allclose(act, g[tag + "fast_act"], rtol=1e-12)
     assert np.isclose(eer, g[tag + "fast_eer"], rtol=1e-12) and np.isclose(prbep, g[tag + "fast_prbep"], rtol=1e-12)
+
+
+def test_two_stage_score_norm_restatements(golden):
+    """ZT- and TZ-norm of the oracle against the reference's predict bodies run on its own ZNorm and
+    TNorm objects (oracle/gen_golden.py gen_score_norm)."""
+    g = golden("score_norm")
+    sc, ct, ec, cc = g["scores"], g["coh_test"], g["enr_coh"], g["coh_coh"]
+    masks = (g["mask_coh_test"], g["mask_enr_coh"], g["mask_coh_coh"])
+    assert np.allclose(O.zt_norm(sc, ct, ec, cc), g["ztnorm"], rtol=1e-10, atol=1e-10)
+    assert np.allclose(O.tz_norm(sc, ct, ec, cc), g["tznorm"], rtol=1e-10, atol=1e-10)
+    assert np.allclose(O.zt_norm(sc, ct, ec, cc, *masks), g["ztnorm_masked"], rtol=1e-10, atol=1e-10)
+    assert np.allclose(O.tz_norm(sc, ct, ec, cc, *masks), g["tznorm_masked"], rtol=1e-10, atol=1e-10)
