@@ -26,14 +26,26 @@ def shard_range(n, part, num_parts):
     return lo, hi
 
 
-def all_gather_lists(local, counts, group=None):
-    """All-gather of per-rank top-k lists [G, rows_of_rank * w] (w entries per row and group, rows
-    contiguous) into [G, sum(rows) * w]; `counts[r]` is the width rank r contributes.  One collective;
-    with a single rank (or no process group) the input is returned unchanged."""
+def settle_for_gloo(t, group=None):
+    """The gloo backend (CPU rehearsals of the sharded path with device tensors) waits for the
+    tensor's stream inside its worker thread; on ROCm that wait does not return while the stream is
+    still busy, so the stream is drained first.  Nothing happens under RCCL."""
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        torch.cuda.synchronize()
+
+
+def all_gather_lists(local, counts, group=None):
+    """All-gather of per-rank top-k lists [G, rows_of_rank * w] (w entries per row and group, rows
+    contiguous) into [G, sum(rows) * w]; `counts[r]` is the width rank r contributes.  One collective;
+    with a single rank, no process group, or a single entry in `counts` (a caller that scores on its
+    own inside a larger job, e.g. rank 0's spot check) the input is returned unchanged."""
+    import torch
+    import torch.distributed as dist
+
+    if len(counts) == 1 or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)
     assert len(counts) == world
@@ -42,7 +54,9 @@ def all_gather_lists(local, counts, group=None):
     send = torch.zeros((k, width), dtype=local.dtype, device=local.device)
     send[:, :local.shape[1]] = local
     recv = torch.empty((world * k, width), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    settle_for_gloo(send, group)
+    # gathered as raw bytes: RCCL process groups have no 16-bit integer type
+    dist.all_gather_into_tensor(recv.view(torch.uint8), send.contiguous().view(torch.uint8), group=group)
     recv = recv.view(world, k, width)
     return torch.cat([recv[r, :, :counts[r]] for r in range(world)], dim=1).contiguous()
 

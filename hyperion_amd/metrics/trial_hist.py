@@ -336,6 +336,9 @@ class TrialHistogram:
         import torch.distributed as dist
 
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            from ..backend import settle_for_gloo
+
+            settle_for_gloo(self.hist, group)
             dist.all_reduce(self.hist, group=group)
             dist.all_reduce(self.mom, group=group)
         return self

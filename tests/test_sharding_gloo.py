@@ -51,7 +51,13 @@ def _worker(rank, world, port, n_rows, k, q):
         counts = [shard_range(n_rows, r, world)[1] - shard_range(n_rows, r, world)[0] for r in range(world)]
         lo, hi = shard_range(n_rows, rank, world)
         got = all_gather_lists(full[:, lo:hi].contiguous(), counts)
-        q.put((rank, bool(torch.equal(got, full)), tuple(got.shape)))
+        ok = bool(torch.equal(got, full))
+        # the dtype of the real top-k lists (16-bit, which RCCL cannot name: they travel as bytes)
+        full16 = (full % 30011).to(torch.int16)
+        ok = ok and bool(torch.equal(all_gather_lists(full16[:, lo:hi].contiguous(), counts), full16))
+        if rank == 0:  # a solo caller inside the job (one entry in counts) must not start a collective
+            ok = ok and all_gather_lists(full16, [n_rows]) is full16
+        q.put((rank, ok, tuple(got.shape)))
     finally:
         dist.destroy_process_group()
 
