@@ -14,12 +14,14 @@ class AHC(HypModel):
         self.method = method
         self.metric = metric
         self.Z = None
+        self.flat_clusters = None
 
     def fit(self, x, mask=None):
         """x: [n, n] scores (host array or device tensor), upper triangle used; mask False at
         (i, j) forbids merging i and j."""
         from scipy.cluster.hierarchy import linkage
 
+        self.flat_clusters = None
         if hasattr(x, "cpu"):
             x = x.cpu().numpy()
         x = np.asarray(x, dtype=np.float64)
@@ -60,3 +62,29 @@ class AHC(HypModel):
         for rank, node in enumerate(sorted(members)):
             labels[members[node]] = rank
         return labels
+
+    def compute_flat_clusters(self):
+        """Labels for every possible number of clusters: row i of `flat_clusters` [n, n] is the
+        assignment with n - i clusters, numbered by rank of the cluster's node number as in
+        get_flat_clusters_from_num_clusters (ahc.py:115-134)."""
+        n = self.Z.shape[0] + 1
+        node = np.arange(n)  # node number of the cluster each point is in
+        flat = np.zeros((n, n), dtype=int)
+        flat[0] = node
+        for i in range(n - 1):
+            node = np.where((node == self.Z[i, 0]) | (node == self.Z[i, 1]), n + i, node)
+            flat[i + 1] = np.unique(node, return_inverse=True)[1]
+        self.flat_clusters = flat
+
+    def evaluate_homogeneity_completeness_tradeoff(self, true_labels):
+        """(homogeneity, completeness) of every row of `flat_clusters` against the true labels
+        (ahc.py:136-158; scikit-learn's scores, on the host as there)."""
+        from sklearn.metrics import completeness_score, homogeneity_score
+
+        from ..hyp_defs import float_cpu
+
+        if self.flat_clusters is None:
+            self.compute_flat_clusters()
+        h = np.array([homogeneity_score(true_labels, row) for row in self.flat_clusters], dtype=float_cpu())
+        c = np.array([completeness_score(true_labels, row) for row in self.flat_clusters], dtype=float_cpu())
+        return h, c

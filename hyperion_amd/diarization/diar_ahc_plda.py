@@ -109,3 +109,14 @@ class DiarAHCPLDA:
     def filter_args(**kwargs):
         valid = ("threshold", "pca_var_r", "do_unsup_cal", "use_bic")
         return {k: kwargs[k] for k in valid if k in kwargs}
+
+    @staticmethod
+    def add_class_args(parser, prefix=None):
+        """hyperion/diarization/diar_ahc_plda.py:186-203."""
+        p1 = "--" if prefix is None else "--" + prefix + "."
+        parser.add_argument(p1 + "threshold", default=0, type=float)
+        parser.add_argument(p1 + "pca-var-r", default=1, type=float)
+        parser.add_argument(p1 + "do-unsup-cal", default=False, action="store_true")
+        parser.add_argument(p1 + "use-bic", default=False, action="store_true")
+
+    add_argparse_args = add_class_args

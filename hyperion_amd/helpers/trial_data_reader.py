@@ -60,3 +60,18 @@ class TrialDataReader(object):
     def filter_args(**kwargs):
         valid = ("tlist_sep", "model_idx", "num_model_parts", "seg_idx", "num_seg_parts", "eval_set")
         return dict((k, kwargs[k]) for k in valid if k in kwargs)
+    @staticmethod
+    def add_class_args(parser, prefix=None):
+        """Options of the evaluation scripts (hyperion/helpers/trial_data_reader.py:86-130)."""
+        p1 = "--" if prefix is None else "--" + prefix + "."
+        parser.add_argument(p1 + "tlist-sep", default=" ", help="trial lists field separator")
+        parser.add_argument(p1 + "model-part-idx", default=1, type=int, help="model part index")
+        parser.add_argument(p1 + "num-model-parts", default=1, type=int,
+                            help="number of parts in which we divide the model list to run evaluation in parallel")
+        parser.add_argument(p1 + "seg-part-idx", default=1, type=int, help="test part index")
+        parser.add_argument(p1 + "num-seg-parts", default=1, type=int,
+                            help="number of parts in which we divide the test list to run evaluation in parallel")
+        parser.add_argument(p1 + "eval-set", type=str.lower, default="enroll-test",
+                            choices=["enroll-test", "enroll-coh", "coh-test", "coh-coh"], help="evaluation subset")
+
+    add_argparse_args = add_class_args

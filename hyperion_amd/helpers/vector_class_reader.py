@@ -154,3 +154,25 @@ class VectorClassReader(object):
         valid_args = ("vlist_sep", "class2int_file", "min_spc", "max_spc", "spc_pruning_mode", "csplit_min_spc",
                       "csplit_max_spc", "csplit_mode", "csplit_overlap", "csplit_once", "vcr_seed")
         return dict((k, kwargs[k]) for k in valid_args if k in kwargs)
+    @staticmethod
+    def add_class_args(parser, prefix=None):
+        """Options of the training scripts (hyperion/helpers/vector_class_reader.py:248-312)."""
+        p1 = "--" if prefix is None else "--" + prefix + "."
+        parser.add_argument(p1 + "vlist-sep", default=" ", help="utt2class file field separator")
+        parser.add_argument(p1 + "class2int-file", default=None, help="file that maps class string to integer")
+        parser.add_argument(p1 + "min-spc", type=int, default=1, help="minimum samples per class")
+        parser.add_argument(p1 + "max-spc", type=int, default=None, help="maximum samples per class")
+        parser.add_argument(p1 + "spc-pruning-mode", default="random", choices=["random", "first", "last"],
+                            help="vector pruning method when spc > max-spc")
+        parser.add_argument(p1 + "csplit-min-spc", type=int, default=None,
+                            help="minimum samples per class when doing class spliting")
+        parser.add_argument(p1 + "csplit-max-spc", type=int, default=None,
+                            help="split one class into subclasses with spc <= csplit-max-spc")
+        parser.add_argument(p1 + "csplit-mode", default="random", type=str.lower,
+                            choices=["sequential", "random", "random_1subclass"], help="class splitting mode")
+        parser.add_argument(p1 + "csplit-overlap", type=float, default=0, help="overlap between subclasses")
+        parser.add_argument(p1 + "no-csplit-once", default=True, action="store_false",
+                            help="class spliting done in each iteration")
+        parser.add_argument(p1 + "vcr-seed", type=int, default=1024, help="seed for rng")
+
+    add_argparse_args = add_class_args

@@ -27,3 +27,12 @@ class VectorReader(object):
     @staticmethod
     def filter_args(**kwargs):
         return dict((k, kwargs[k]) for k in ("vlist_sep",) if k in kwargs)
+    @staticmethod
+    def add_class_args(parser, prefix=None):
+        """hyperion/helpers/vector_reader.py:48-60.  The reference nests the option in a
+        jsonargparse sub-parser when a prefix is given; with plain argparse the same option is spelled
+        `--<prefix>.vlist-sep`."""
+        p1 = "--" if prefix is None else "--" + prefix + "."
+        parser.add_argument(p1 + "vlist-sep", default=" ", help="utterance file field separator")
+
+    add_argparse_args = add_class_args

@@ -39,8 +39,24 @@ class HypModel(object):
     def init_to_false(self):
         self._is_init = False
 
+    # the reference declares these three abstract (hyperion/hyp_model.py:33-43); models that train
+    # override them
+    def initialize(self):
+        raise NotImplementedError("%s has no initialize()" % type(self).__name__)
+
+    def fit(self, x, sample_weights=None, x_val=None, sample_weights_val=None):
+        raise NotImplementedError("%s has no fit()" % type(self).__name__)
+
+    def fit_generator(self, x, x_val=None):
+        raise NotImplementedError("%s has no fit_generator()" % type(self).__name__)
+
     def get_config(self):
         return {"class_name": self.__class__.__name__, "name": self.name}
+
+    @staticmethod
+    def load_config_from_json(json_str):
+        """hyperion/hyp_model.py:133-135."""
+        return json.loads(json_str)
 
     def to_json(self, **kwargs):
         """The configuration as JSON text; numpy scalars become Python numbers, types their names

@@ -220,6 +220,35 @@ class PLDA(PLDABase):
             self.U = chol_Cov_z @ U
 
     # ---- sampling, adaptation (plda.py:541-589) --------------------------------------------------
+    def compute_aux(self):
+        """Sets the reference's auxiliary attributes from the current parameters (plda.py:77-89):
+        _DU, _J, _Lz, _mult_iLz, _log_Lz, the within-class precision _W (Woodbury form of
+        (diag(1/D) + U^T U)^-1) and the products _VW [x_dim, y_dim], _VWV.  Scoring and training here
+        fold the parameters themselves (fingerprinted caches), so nothing reads these back; they are
+        for callers that did."""
+        from ...utils.math import invert_pdmat
+
+        a = self._aux()
+        f = lambda v: np.asarray(v, dtype=np.float64)  # noqa: E731
+        self._DU, self._J, self._W = a["DU"], a["J"], a["W"]
+        self._Lz = np.eye(a["DU"].shape[0]) + a["DU"] @ f(self.U).T
+        self._mult_iLz, _, self._log_Lz = invert_pdmat(self._Lz, right_inv=True, return_logdet=True)
+        self._VW, self._VWV = self._WV()
+
+    def log_probx_g_y(self, x, y):
+        """log p(x_i | y_i) with the channel factor integrated out (plda.py:407-417): the precision
+        is W = (diag(1/D) + U^T U)^-1 and log|W| = sum log D - log|I + U D U^T|."""
+        a = self._aux()
+        logdet_W = float(np.sum(np.log(np.asarray(self.D, dtype=np.float64)))) - a["log_Lz"]
+        logp = self._row_logp(self._residual(x, (y, self.V)), a["W"], logdet_W)
+        return engine.to_host(logp, float_cpu())
+
+    def log_probx_g_yz(self, x, y, z):
+        """log p(x_i | y_i, z_i) (plda.py:419-428): diagonal precision D around mu + y V + z U."""
+        D = np.asarray(self.D, dtype=np.float64)
+        logp = self._row_logp(self._residual(x, (y, self.V), (z, self.U)), D, float(np.sum(np.log(D))))
+        return engine.to_host(logp, float_cpu())
+
     def sample(self, num_classes, num_samples_per_class, rng=None, seed=1024):
         """Host draw with numpy's generator, in the reference's order; the residual is divided by D
         itself, as it is there (plda.py:541-562)."""

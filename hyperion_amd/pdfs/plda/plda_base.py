@@ -234,6 +234,23 @@ class PLDABase(HypModel):
         return PLDABase._stats_hard_device(x, class_ids, sample_weight, scale_factor).host()
 
     @staticmethod
+    def compute_stats_hard_v0(x, class_ids, sample_weight=None, scal_factor=None):
+        """The reference's earlier statement of compute_stats_hard through a one-hot posterior
+        matrix (plda_base.py:276-282); the same statistics, so the same device path without the
+        [n, classes] matrix."""
+        return PLDABase.compute_stats_hard(x, class_ids, sample_weight, scal_factor)
+
+    @staticmethod
+    def center_stats(D, mu):
+        """Statistics of the vectors shifted by -mu, from the statistics themselves
+        (plda_base.py:284-290): Fc = F - N mu^T, Sc = S - (sum F) mu^T - mu (sum F)^T + (sum N) mu mu^T.
+        Host algebra on the [classes, d] and [d, d] statistics; nothing is modified in place."""
+        N, F, S = D
+        N, F, S, mu = (np.asarray(a, dtype=np.float64) for a in (N, F, S, mu))
+        Fmu = np.outer(np.sum(F, axis=0), mu)
+        return N, F - np.outer(N, mu), S - Fmu - Fmu.T + np.sum(N) * np.outer(mu, mu)
+
+    @staticmethod
     def compute_stats_soft(x, p_theta, sample_weight=None, scal_factor=None):
         """Statistics from class posteriors p_theta [n, C] (plda_base.py:236-246): N = sum_s p,
         F = p^T x, S = x^T diag(sum_c p) x.  (The reference scales the caller's p_theta in place
@@ -392,6 +409,35 @@ class PLDABase(HypModel):
         D_val = None if x_val is None else self._train_stats(x_val, class_ids_val, ptheta_val, sample_weight_val)
         return self._em_epochs(D, D_val, epochs, ml_md, md_epochs, also=D0)
 
+    # declared abstract by the reference (plda_base.py:353-355, 365-367); every model overrides
+    # `sample`, and none overrides the misspelt `weigthed_avg_model` (they define weighted_avg_model)
+    def sample(self, num_classes, num_samples_per_class, rng=None, seed=1024):
+        raise NotImplementedError("%s has no sample()" % type(self).__name__)
+
+    def weigthed_avg_model(self, plda):
+        raise NotImplementedError("use weighted_avg_model(plda, w_mu, w_B, w_W)")
+
+    def _row_logp(self, delta, Wq, logdet_W):
+        """Row-wise Gaussian log-density (-d log 2 pi + log|W| - delta W delta^T) / 2 on the device in
+        float64; delta a device [n, d] tensor, Wq the precision as [d, d] or a diagonal [d]."""
+        torch = engine.require_gpu()
+        if np.ndim(Wq) == 1:
+            Wd = torch.from_numpy(np.ascontiguousarray(Wq, dtype=np.float64)).to(delta.device)
+            quad = (delta * delta * Wd).sum(dim=1)
+        else:
+            quad = (engine.gemm64(delta, np.ascontiguousarray(np.asarray(Wq, dtype=np.float64).T)) * delta).sum(dim=1)
+        logp = 0.5 * (-delta.shape[1] * np.log(2 * np.pi) + logdet_W - quad)
+        return logp
+
+    def _residual(self, x, *terms):
+        """x - mu - sum_i y_i M_i on the device in float64 (terms = (y_i, M_i) pairs, M_i [K_i, d])."""
+        torch = engine.require_gpu()
+        Y = np.concatenate([np.asarray(y, dtype=np.float64) for y, _ in terms], axis=1)
+        M = np.concatenate([np.asarray(m, dtype=np.float64) for _, m in terms], axis=0)  # [sum K, d]
+        delta = engine.gemm64(Y, np.ascontiguousarray(-M.T), bias=-np.asarray(self.mu, dtype=np.float64))
+        X = x if isinstance(x, torch.Tensor) else engine.upload64(np.asarray(x, dtype=np.float64))
+        return delta.add_(X.to(torch.float64))
+
     def weigthed_avg_params(self, mu, w_mu):
         """The mean part of the model interpolation, under the reference's spelling
         (plda_base.py:362-363)."""
@@ -461,6 +507,24 @@ class PLDABase(HypModel):
         G1 = plan.prologue(self._pooled_mean(x1, ids1), SIDE_ENROL)
         G2 = plan.prologue(engine.upload(x2), SIDE_TEST)
         return self._result(engine.score(G1, G2), x1, x2)
+
+    # the pooling variants under the names the reference gives them (plda_base.py:306-351)
+    def llr_NvsM_vavg(self, D1, D2, do_lnorm=True):
+        """Scores of the class means F / N of two statistics tuples, length-normalised first when
+        do_lnorm (plda_base.py:306-314)."""
+        return self.llr_NvsM(D1, D2, method="vavg-lnorm" if do_lnorm else "vavg")
+
+    def llr_NvsM_savg(self, x1, ids1, x2, ids2):
+        """Segment-level scores averaged over the classes of both sides (plda_base.py:316-322)."""
+        return self._llr_savg(x1, ids1, x2, ids2)
+
+    def llr_Nvs1_vavg(self, D1, x2, do_lnorm=True):
+        """plda_base.py:338-345."""
+        return self.llr_Nvs1(D1, x2, method="vavg-lnorm" if do_lnorm else "vavg")
+
+    def llr_Nvs1_savg(self, x1, ids1, x2):
+        """plda_base.py:347-351."""
+        return self._llr_savg(x1, ids1, x2, None)
 
     def _llr_savg(self, x1, ids1, x2, ids2):
         """Score averaging (plda_base.py:316-322, 347-351).  The score is bilinear in the packed

@@ -191,6 +191,16 @@ class SPLDA(PLDABase):
             self.V = sla.cholesky(Py / M - np.outer(mu_y, mu_y), lower=False) @ self.V
 
     # ---- sampling, adaptation (splda.py:381-419) ------------------------------------------------
+    def log_probx_g_y(self, x, y):
+        """log p(x_i | y_i) of every row, x [n, x_dim], y [n, y_dim] (splda.py:264-273):
+        (-d log 2 pi + log|W| - (x - mu - y V) W (x - mu - y V)^T) / 2.  Residual and quadratic form
+        on the device in float64, log|W| from the host Cholesky factor."""
+        from ...utils.math import logdet_pdmat
+
+        W = self._W_full()
+        logp = self._row_logp(self._residual(x, (y, self.V)), W, logdet_pdmat(W))
+        return engine.to_host(logp, float_cpu())
+
     def sample(self, num_classes, num_samples_per_class, rng=None, seed=1024):
         """Host draw with numpy's generator, in the reference's order (splda.py:381-399)."""
         from scipy import linalg as sla

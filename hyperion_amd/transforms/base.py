@@ -41,6 +41,50 @@ class AffineTransform(HypModel):
         return cls(mu=params["mu"], T=params["T"], name=config["name"])
 
 
+    # ---- bare matrix files and command-line plumbing ------------------------------------------
+    @classmethod
+    def load_mat(cls, file_path):
+        """mu and T from the top level of an HDF5 file, at float32 precision as the reference reads
+        them (e.g. hyperion/transforms/cent_whiten.py:79-84)."""
+        from ..io.hdf5_lite import Hdf5File
+
+        f = Hdf5File(file_path)
+        return cls(np.asarray(f["mu"]).astype("float32"), np.asarray(f["T"]).astype("float32"))
+
+    def save_mat(self, file_path):
+        """mu and T as top-level datasets in their own precision (cent_whiten.py:86-89)."""
+        from ..io.hdf5_write import File
+
+        with File(file_path, "w") as f:
+            f.create_dataset("mu", data=np.asarray(self.mu))
+            f.create_dataset("T", data=np.asarray(self.T))
+
+    _valid_args = ("update_mu", "update_T", "name")
+    _default_name = "lnorm"  # what the reference's parsers say for CentWhiten and LNorm alike
+
+    @classmethod
+    def filter_args(cls, **kwargs):
+        """The constructor arguments among a parsed command line (cent_whiten.py:91-94)."""
+        return dict((k, kwargs[k]) for k in cls._valid_args if k in kwargs)
+
+    @classmethod
+    def add_class_args(cls, parser, prefix=None):
+        """Options of the training scripts (cent_whiten.py:96-119); `type=bool` as in the
+        reference, i.e. any non-empty value reads as True."""
+        p1 = "--" if prefix is None else "--" + prefix + "."
+        parser.add_argument(p1 + "update-mu", default=True, type=bool, help="updates centering parameter")
+        parser.add_argument(p1 + "update-T", default=True, type=bool, help="updates whitening parameter")
+        cls._add_own_args(parser, p1)
+
+    @classmethod
+    def _add_own_args(cls, parser, p1):
+        parser.add_argument(p1 + "name", default=cls._default_name)
+
+    @classmethod
+    def add_argparse_args(cls, parser, prefix=None):
+        return cls.add_class_args(parser, prefix)
+
+
 def chain_plan(transforms, d_in, cache_owner):
     key = (d_in,) + tuple(t._params_key() for t in transforms)
     if cache_owner._plan is None or cache_owner._plan_key != key:

@@ -19,6 +19,42 @@ class PCA(AffineTransform):
             raise ValueError("PCA.predict needs a projection matrix T")
         return super()._step()
 
+    @staticmethod
+    def get_pca_dim_for_var_ratio(x, var_r=1, min_dim=2):
+        """Number of directions that hold the share `var_r` of the (uncentred) energy of the rows
+        of x, at least min_dim (pca.py:44-59).  The squared singular values of x are the eigenvalues
+        of its Gram matrix, which comes from the device; with var_r = 1 the answer is the rank of x,
+        counted like numpy's matrix_rank (singular values above max(n, d) eps times the largest) -
+        on the Gram matrix only values above sqrt(eps) times the largest can be told from zero, so
+        the count uses that threshold when it is the larger one."""
+        import numpy as np
+
+        from .. import engine
+
+        n, d = x.shape
+        C, _ = engine.gram64(x)
+        ev = np.flip(np.linalg.eigvalsh(C.cpu().numpy()))
+        ev = np.maximum(ev, 0.0)[:min(n, d)]
+        if var_r == 1:
+            eps = np.finfo(np.float64).eps
+            tol = max(max(n, d) * eps, np.sqrt(d * eps)) * np.sqrt(ev[0]) if ev.size else 0.0
+            rank = int(np.sum(np.sqrt(ev) > tol))
+        else:
+            share = np.cumsum(ev)
+            share = share / share[-1]
+            rank = int(np.where(share > var_r)[0][0])
+        return max(min_dim, rank)
+
+    _valid_args = ("update_mu", "update_T", "name", "pca_dim", "pca_var_r")
+
+    @classmethod
+    def _add_own_args(cls, parser, p1):
+        """pca.py:166-178; the name option has no prefix there."""
+        parser.add_argument(p1 + "pca-dim", default=None, type=int, help="output dimension of PCA")
+        parser.add_argument(p1 + "pca-var-r", default=None, type=int,
+                            help="proportion of variance to keep when choosing the PCA dimension")
+        parser.add_argument("--name", dest="name", default="pca")
+
     def fit(self, x=None, sample_weight=None, mu=None, S=None):
         """Mean and leading eigenvectors of the covariance, largest first, first row non-negative;
         pca_var_r picks the dimension that explains that share of the variance, whiten scales the

@@ -29,6 +29,15 @@ class SCPList(object):
         self.range_spec = range_spec
         self._index = None
 
+    def validate(self):
+        """Re-checks attributes that were assigned after construction (scp_list.py:36-64): array
+        types, equal lengths, an empty range list read as none."""
+        self.__init__(self.key, self.file_path, self.offset, self.range_spec)
+
+    def __cmp__(self, other):
+        """0 when equal, 1 otherwise (scp_list.py:436-440; a Python 2 protocol nothing calls)."""
+        return 0 if self.__eq__(other) else 1
+
     def copy(self):
         return deepcopy(self)
 

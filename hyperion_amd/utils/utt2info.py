@@ -17,6 +17,14 @@ class Utt2Info(object):
         assert self._fields.ndim == 2 and len(self._key) == len(self._fields) and self._fields.shape[1] >= 1
         self._index = None
 
+    def validate(self):
+        """A key column and at least one info column of the same length (utt2info.py:32-36)."""
+        assert self._fields.ndim == 2 and len(self._key) == len(self._fields) and self._fields.shape[1] >= 1
+
+    def __cmp__(self, other):
+        """0 when equal, 1 otherwise (utt2info.py:282-286)."""
+        return 0 if self.__eq__(other) else 1
+
     @classmethod
     def create(cls, key, info):
         return cls(key, info)

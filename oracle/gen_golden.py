@@ -352,6 +352,101 @@ def gen_project():
     print("project ok")
 
 
+def gen_model_eval():
+    """Conditional log-densities, statistics centring, the named pooling variants and the PCA
+    dimension chooser of the reference on seeded inputs."""
+    rng = np.random.RandomState(31)
+    d, K = 12, 4
+    ms = small_models(d, K, 9)
+    n = 37
+    x, y, z = rng.randn(n, d), rng.randn(n, K), rng.randn(n, 3)
+    out = dict(x=x, y=y, z=z)
+    r = ref_model(ms["splda"])
+    out["splda_logp_y"] = r.log_probx_g_y(x, y)
+    close(O.splda_log_probx_g_y(ms["splda"], x, y), out["splda_logp_y"])
+    r = ref_model(ms["plda"])
+    # PLDA.log_probx_g_y itself stops with a ValueError unless n == x_dim (plda.py:414 applies the
+    # left inverse to row vectors); its evident intent is SPLDA's density with the within-class
+    # precision of compute_aux, which is what the reference is asked for here
+    try:
+        r.log_probx_g_y(x, y)
+        raise AssertionError("the reference's PLDA.log_probx_g_y ran: pin it directly")
+    except ValueError:
+        pass
+    out["plda_logp_y"] = R.SPLDA(mu=ms["plda"]["mu"].copy(), V=ms["plda"]["V"].copy(),
+                                 W=np.asarray(r._W).copy()).log_probx_g_y(x, y)
+    out["plda_logp_yz"] = r.log_probx_g_yz(x, y, z)
+    close(O.plda_log_probx_g_y(ms["plda"], x, y), out["plda_logp_y"])
+    close(O.plda_log_probx_g_yz(ms["plda"], x, y, z), out["plda_logp_yz"])
+    for k in ("_DU", "_J", "_Lz", "_log_Lz", "_W", "_VW", "_VWV"):
+        out["plda_aux" + k] = np.asarray(getattr(r, k))
+    # centring of statistics
+    ids = rng.randint(0, 9, n)
+    ids[:9] = np.arange(9)
+    D = R.SPLDA.compute_stats_hard(x, ids)
+    mu = rng.randn(d)
+    Nc, Fc, Sc = R.SPLDA.center_stats(D, mu)
+    for a, b in zip(O.center_stats(O.compute_stats_hard(x, ids), mu), (Nc, Fc, Sc)):
+        close(a, b)
+    D0 = R.SPLDA.compute_stats_hard_v0(x, ids)
+    out.update(ids=ids, cs_mu=mu, cs_N=Nc, cs_F=Fc, cs_S=Sc, v0_N=D0[0], v0_F=D0[1], v0_S=D0[2])
+    # the pooling variants under their own names
+    x2 = rng.randn(21, d)
+    ids2 = rng.randint(0, 5, 21)
+    ids2[:5] = np.arange(5)
+    for name, m in ms.items():
+        r = ref_model(m)
+        D1 = r.compute_stats_hard(x, ids)
+        D2 = r.compute_stats_hard(x2, ids2)
+        for ln in (True, False):
+            tag = "%s_%s" % (name, "ln" if ln else "raw")
+            out["nvsm_vavg_" + tag] = r.llr_NvsM_vavg(D1, D2, do_lnorm=ln)
+            out["nvs1_vavg_" + tag] = r.llr_Nvs1_vavg(D1, x2.copy(), do_lnorm=ln)
+            meth = "vavg-lnorm" if ln else "vavg"
+            close(O.llr_NvsM(m, x, x2, ids, ids2, method=meth), out["nvsm_vavg_" + tag])
+            close(O.llr_Nvs1(m, x, x2, ids, method=meth), out["nvs1_vavg_" + tag])
+        out["nvsm_savg_" + name] = r.llr_NvsM_savg(x, ids, x2, ids2)
+        out["nvs1_savg_" + name] = r.llr_Nvs1_savg(x, ids, x2)
+        close(O.llr_NvsM(m, x, x2, ids, ids2, method="savg"), out["nvsm_savg_" + name])
+        close(O.llr_Nvs1(m, x, x2, ids, method="savg"), out["nvs1_savg_" + name])
+        out.update(flat(name + "_", m))
+    out.update(x2=x2, ids2=ids2)
+    # PCA dimension chooser: full rank, rank deficient, energy shares
+    xr = rng.randn(50, 5) @ rng.randn(5, d)
+    out["pca_x_full"], out["pca_x_def"] = x, xr
+    cases = []
+    for tag, xx in (("full", x), ("def", xr)):
+        for var_r in (1, 0.5, 0.9, 0.99):
+            for min_dim in (2, 7):
+                got = R.PCA.get_pca_dim_for_var_ratio(xx, var_r, min_dim)
+                assert got == O.pca_dim_for_var_ratio(xx, var_r, min_dim)
+                cases.append((0 if tag == "full" else 1, var_r, min_dim, got))
+    out["pca_dim_cases"] = np.array(cases, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "model_eval.npz"), **out)
+    print("model eval ok")
+
+
+def gen_ahc_levels():
+    """Every level of the reference's AHC tree (hyperion/clustering/ahc.py:115-158) on a seeded score
+    matrix: the [n, n] table of flat clusters and the homogeneity / completeness curve."""
+    from hyperion.clustering.ahc import AHC
+
+    rng = np.random.RandomState(77)
+    n = 23
+    true = rng.randint(0, 4, n)
+    emb = rng.randn(4, 6)[true] * 2 + rng.randn(n, 6)
+    scores = emb @ emb.T
+    a = AHC(method="average", metric="llr")
+    a.fit(scores.copy())
+    a.compute_flat_clusters()
+    h, c = a.evaluate_homogeneity_completeness_tradeoff(true)
+    for i in range(n):  # the table agrees with the single-level method of the same class
+        assert np.array_equal(a.flat_clusters[i], a.get_flat_clusters_from_num_clusters(n - i))
+    np.savez_compressed(os.path.join(OUT, "ahc_levels.npz"), scores=scores, true=true, Z=a.Z,
+                        flat_clusters=a.flat_clusters, homogeneity=h, completeness=c)
+    print("ahc levels ok")
+
+
 def gen_training_stats():
     """Whitening / LDA fits and PLDA sufficient statistics of the reference on labelled vectors
     (hyperion/transforms/cent_whiten.py:35-62, sb_sw.py:25-50, lda.py:36-68,
@@ -696,6 +791,8 @@ def gen_diarization():
 
 
 if __name__ == "__main__":
+    gen_model_eval()
+    gen_ahc_levels()
     os.makedirs(OUT, exist_ok=True)
     gen_frplda_training()
     gen_plda_training()

@@ -222,6 +222,56 @@ def compute_stats_hard(x, class_ids):
     return N, F, np.dot(x.T, x)
 
 
+def center_stats(D, mu):
+    """hyperion/pdfs/plda/plda_base.py:284-290."""
+    N, F, S = D
+    Fc = F - np.outer(N, mu)
+    Fmu = np.outer(np.sum(F, axis=0), mu)
+    Sc = S - Fmu - Fmu.T + np.sum(N) * np.outer(mu, mu)
+    return N, Fc, Sc
+
+
+def splda_log_probx_g_y(m, x, y):
+    """hyperion/pdfs/plda/splda.py:264-273."""
+    logW = logdet_pdmat(m["W"])
+    delta = x - m["mu"] - np.dot(y, m["V"])
+    logp = -x.shape[-1] * np.log(2 * np.pi) + logW - np.sum(np.dot(delta, m["W"]) * delta, axis=-1)
+    return logp / 2
+
+
+def plda_log_probx_g_y(m, x, y):
+    """hyperion/pdfs/plda/plda.py:407-417: precision given through its inverse diag(1/D) + U^T U."""
+    iW = np.diag(1 / m["D"]) + np.dot(m["U"].T, m["U"])
+    R = chol_upper(iW)
+    logiW = 2.0 * np.sum(np.log(np.diag(R)))
+    delta = x - m["mu"] - np.dot(y, m["V"])
+    Wdelta = sla.cho_solve((R, False), delta.T).T
+    logp = -x.shape[-1] * np.log(2 * np.pi) - logiW - np.sum(Wdelta * delta, axis=-1)
+    return logp / 2
+
+
+def plda_log_probx_g_yz(m, x, y, z):
+    """hyperion/pdfs/plda/plda.py:419-428."""
+    logD = np.sum(np.log(m["D"]))
+    delta = x - m["mu"] - np.dot(y, m["V"]) - np.dot(z, m["U"])
+    logp = -x.shape[-1] * np.log(2 * np.pi) + logD - np.sum(m["D"] * delta ** 2, axis=-1)
+    return logp / 2
+
+
+def pca_dim_for_var_ratio(x, var_r=1, min_dim=2):
+    """hyperion/transforms/pca.py:44-59."""
+    if var_r == 1:
+        rank = np.linalg.matrix_rank(x)
+        if rank <= min_dim:
+            rank = np.linalg.matrix_rank(np.dot(x.T, x))
+    else:
+        sv = sla.svd(x, compute_uv=False)
+        Ecc = np.cumsum(sv ** 2)
+        Ecc = Ecc / Ecc[-1]
+        rank = np.where(Ecc > var_r)[0][0]
+    return max(min_dim, rank)
+
+
 def _book_pair(F1, F2, n1, n2, proj_non, proj_tar, logL):
     """One (N1_i, N2_j) block of llr_NvsM_book (splda.py:332-376).  proj_non(n) / proj_tar(n)
     map first-order stats to gamma_non / gamma_tar for count n."""
