@@ -124,3 +124,79 @@ def fast_eval_dcf_eer(tar, non, prior, normalize_dcf=True, return_probs=False):
         return min_dcf, act_dcf, eer, prbep
     idx = np.argmin(dcf, axis=-1)
     return min_dcf, act_dcf, eer, prbep, p_miss[idx], p_fa[idx], act_pmiss, act_pfa
+
+
+def _merged_order(tar, non):
+    """(labels in ascending score order, the sorting permutation) of the concatenation [tar, non],
+    stable - the order numpy's mergesort gives the reference - sorted on the device in float64."""
+    torch = engine.require_gpu()
+    f = lambda a: (a.detach().reshape(-1).to(device="cuda", dtype=torch.float64) if isinstance(a, torch.Tensor)  # noqa: E731
+                   else torch.from_numpy(np.ascontiguousarray(np.asarray(a).reshape(-1), dtype=np.float64)).cuda())
+    t, n = f(tar), f(non)
+    order = torch.sort(torch.cat((t, n)), stable=True).indices
+    return order < t.numel(), order
+
+
+def compute_roc(true_scores, false_scores):
+    """The observed ROC: (p_miss, p_fa) after every score in ascending order, preceded by the point
+    (0, 1) of the threshold below all scores (roc.py:13-51).  Sort and running counts on the
+    device."""
+    torch = engine.require_gpu()
+    is_tar, _ = _merged_order(true_scores, false_scores)
+    num_true = int(is_tar.sum().item())
+    num_false = is_tar.numel() - num_true
+    assert num_true > 0 and num_false > 0
+    # running counts on the device as integers; the two divisions on the host, where they round as
+    # the reference's do
+    sumtrue = torch.cumsum(is_tar.to(torch.int64), dim=0).cpu().numpy()
+    sumfalse = num_false - (np.arange(1, sumtrue.size + 1) - sumtrue)
+    p_miss = np.zeros(sumtrue.size + 1)
+    p_fa = np.ones(sumtrue.size + 1)
+    p_miss[1:] = sumtrue / num_true
+    p_fa[1:] = sumfalse / num_false
+    return p_miss, p_fa
+
+
+def pavx(y):
+    """Pool-adjacent-violators: the non-decreasing sequence closest to y in squared error, as
+    (ghat [n], width of every constant block, its height) (utils.py:30-94).  A block joins its left
+    neighbour while that neighbour is not lower; the joined height is updated as
+    left + (width / new_width) (height - left), the reference's own arithmetic, so equal inputs give
+    bit-equal outputs.  Sequential by nature: host code."""
+    y = np.asarray(y, dtype=np.float64).reshape(-1)
+    assert y.size > 0
+    heights, widths = [], []
+    for v in y.tolist():
+        w = 1
+        while heights and heights[-1] >= v:
+            left, lw = heights.pop(), widths.pop()
+            v = left + (w / (lw + w)) * (v - left)
+            w += lw
+        heights.append(v)
+        widths.append(w)
+    width = np.array(widths, dtype=int)
+    height = np.array(heights, dtype=np.float64)
+    return np.repeat(height, width), width, height
+
+
+def opt_loglr(tar, non, method="laplace"):
+    """Non-parametric score to log-likelihood-ratio mapping (utils.py:97-150): isotonic regression of
+    the target indicator over the sorted scores, with one target and one non-target added at each end
+    for method "laplace"; returns (tar_llr, non_llr) in the callers' order.  The sort runs on the
+    device, the pooling on the host."""
+    ntar, nnon = np.size(tar), np.size(non)
+    n = ntar + nnon
+    is_tar, order = _merged_order(tar, non)
+    p_ideal = is_tar.cpu().numpy().astype(np.float64)
+    order = order.cpu().numpy()
+    if method == "laplace":
+        p_ideal = np.concatenate(([1, 0], p_ideal, [1, 0]))
+    p_opt = pavx(p_ideal)[0]
+    if method == "laplace":
+        p_opt = p_opt[2:-2]
+    with np.errstate(divide="ignore"):
+        llr = np.log(p_opt) - np.log(1 - p_opt) - np.log(ntar / nnon)
+    llr += 1e-6 * np.arange(n) / n
+    out = np.empty(n, dtype=np.float64)
+    out[order] = llr
+    return out[:ntar], out[ntar:]

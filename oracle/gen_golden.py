@@ -447,6 +447,39 @@ def gen_ahc_levels():
     print("ahc levels ok")
 
 
+def gen_roc_cal_cos():
+    """The observed ROC, pool-adjacent-violators on general sequences, the non-parametric
+    calibration and cosine scoring of the reference on seeded inputs (ties included)."""
+    from hyperion.metrics.roc import compute_roc
+    from hyperion.metrics.utils import opt_loglr, pavx
+
+    rng = np.random.RandomState(53)
+    tar = np.round(rng.randn(300) + 1.5, 1)  # one decimal: many ties within and across the classes
+    non = np.round(rng.randn(2000) - 0.5, 1)
+    out = dict(tar=tar, non=non)
+    out["roc_pmiss"], out["roc_pfa"] = compute_roc(tar, non)
+    for a, b in zip(O.compute_roc(tar, non), (out["roc_pmiss"], out["roc_pfa"])):
+        assert np.array_equal(a, b)
+    y = np.round(rng.randn(500).cumsum() / 5 + rng.randn(500), 2)
+    out["pav_y"] = y
+    out["pav_ghat"], out["pav_width"], out["pav_height"] = pavx(y)
+    for a, b in zip(O.pavx(y), (out["pav_ghat"], out["pav_width"], out["pav_height"])):
+        assert np.array_equal(a, b)
+    for method in ("laplace", "raw"):
+        with np.errstate(divide="ignore"):
+            t, n = opt_loglr(tar, non, method)
+        out["cal_tar_" + method], out["cal_non_" + method] = t, n
+        a, b = O.opt_loglr(tar, non, method)
+        assert np.array_equal(a, t) and np.array_equal(b, n)
+    for d in (512, 37):
+        x1, x2 = rng.randn(29, d), rng.randn(41, d) * np.exp(rng.randn(41, 1))
+        out["cos%d_x1" % d], out["cos%d_x2" % d] = x1, x2
+        out["cos%d" % d] = R.math.cosine_scoring(x1, x2)
+        close(O.cosine_scoring(x1, x2), out["cos%d" % d], 1e-14)
+    np.savez_compressed(os.path.join(OUT, "roc_cal_cos.npz"), **out)
+    print("roc / calibration / cosine ok")
+
+
 def gen_training_stats():
     """Whitening / LDA fits and PLDA sufficient statistics of the reference on labelled vectors
     (hyperion/transforms/cent_whiten.py:35-62, sb_sw.py:25-50, lda.py:36-68,
@@ -792,6 +825,7 @@ def gen_diarization():
 
 if __name__ == "__main__":
     gen_model_eval()
+    gen_roc_cal_cos()
     gen_ahc_levels()
     os.makedirs(OUT, exist_ok=True)
     gen_frplda_training()

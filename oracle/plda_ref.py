@@ -1288,3 +1288,48 @@ def fast_eval_dcf_eer(tar, non, prior, normalize_dcf=True):
     dcf = compute_dcf(p_miss, p_fa, prior, normalize_dcf)
     return (np.min(dcf, axis=-1), compute_act_dcf(tar, non, prior, normalize_dcf)[0], rocch2eer(p_miss, p_fa),
             rocch2eer(p_miss * len(tar), p_fa * len(non)))
+
+
+def compute_roc(true_scores, false_scores):
+    """hyperion/metrics/roc.py:13-51."""
+    num_true, num_false = len(true_scores), len(false_scores)
+    total = num_true + num_false
+    scores = np.hstack((true_scores, false_scores))
+    labels = np.zeros_like(scores)
+    labels[:num_true] = 1
+    labels = labels[np.argsort(scores, kind="mergesort")]
+    sumtrue = np.cumsum(labels)
+    sumfalse = num_false - (np.arange(total) + 1 - sumtrue)
+    p_miss, p_fa = np.zeros(total + 1), np.zeros(total + 1)
+    p_fa[0] = 1.0
+    p_miss[1:] = sumtrue / num_true
+    p_fa[1:] = sumfalse / num_false
+    return p_miss, p_fa
+
+
+def opt_loglr(tar, non, method="laplace"):
+    """hyperion/metrics/utils.py:97-150."""
+    ntar, nnon = len(tar), len(non)
+    n = ntar + nnon
+    scores = np.concatenate((tar, non))
+    p_ideal = np.zeros(n, dtype=F64)
+    p_ideal[:ntar] = 1
+    sort_idx = np.argsort(scores, kind="mergesort")
+    p_ideal = p_ideal[sort_idx]
+    if method == "laplace":
+        p_ideal = np.concatenate(([1, 0], p_ideal, [1, 0]))
+    p_opt, _, _ = pavx(p_ideal)
+    if method == "laplace":
+        p_opt = p_opt[2:-2]
+    with np.errstate(divide="ignore"):
+        llr = np.log(p_opt) - np.log(1 - p_opt) - np.log(ntar / nnon)
+    llr += 1e-6 * np.arange(n) / n
+    llr[sort_idx] = llr
+    return llr[:ntar], llr[ntar:]
+
+
+def cosine_scoring(x1, x2):
+    """hyperion/utils/math.py:349-356."""
+    x1 = x1 / np.sqrt(np.sum(x1 ** 2, axis=-1, keepdims=True))
+    x2 = x2 / np.sqrt(np.sum(x2 ** 2, axis=-1, keepdims=True))
+    return np.dot(x1, x2.T)

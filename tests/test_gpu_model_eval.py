@@ -72,3 +72,36 @@ def test_one_hot_statistics_and_pca_dimension(golden):
     for tag, var_r, min_dim, want in g["pca_dim_cases"]:
         xx = g["pca_x_full"] if tag == 0 else g["pca_x_def"]
         assert PCA.get_pca_dim_for_var_ratio(xx, var_r if var_r != 1 else 1, int(min_dim)) == int(want), (tag, var_r)
+
+
+def test_observed_roc_and_calibration_match_reference(golden):
+    from hyperion_amd.metrics import compute_roc, opt_loglr
+
+    g = golden("roc_cal_cos")
+    tar, non = g["tar"], g["non"]
+    pm, pf = compute_roc(tar, non)
+    assert np.array_equal(pm, g["roc_pmiss"]) and np.array_equal(pf, g["roc_pfa"])  # counts: exact
+    for method in ("laplace", "raw"):
+        t, n = opt_loglr(tar, non, method)
+        assert np.array_equal(t, g["cal_tar_" + method]) and np.array_equal(n, g["cal_non_" + method])
+    import torch
+
+    pm2, pf2 = compute_roc(torch.from_numpy(tar).cuda(), torch.from_numpy(non).cuda())  # device arrays in
+    assert np.array_equal(pm2, pm) and np.array_equal(pf2, pf)
+
+
+@pytest.mark.parametrize("d", [512, 37])
+def test_cosine_scoring_matches_reference(golden, d):
+    import torch
+
+    from hyperion_amd.utils.math import cosine_scoring
+
+    g = golden("roc_cal_cos")
+    x1, x2, ref = g["cos%d_x1" % d], g["cos%d_x2" % d], g["cos%d" % d]
+    got = cosine_scoring(x1, x2)
+    assert got.dtype == np.float64 and got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) <= 1e-5  # |cos| <= 1: absolute = the path's mixed tolerance
+    dev = cosine_scoring(torch.from_numpy(x1).float().cuda(), torch.from_numpy(x2).float().cuda())
+    assert dev.is_cuda and np.max(np.abs(dev.cpu().numpy() - ref)) <= 1e-5
+    with pytest.raises(ValueError):
+        cosine_scoring(x1, x2[:, :-1])

@@ -142,3 +142,31 @@ def test_list_and_trial_tables_keep_the_old_comparison_protocol():
     assert n1.__cmp__(n1.copy()) == 0 and n1.__cmp__(TrialNdx(["m1", "m2"], ["t1", "t2"], ~mask)) == 1
     k = TrialKey(["m1", "m2"], ["t1", "t2"], mask, ~mask)
     assert k.__cmp__(k.copy()) == 0
+
+
+def test_oracle_roc_calibration_cosine_match_reference(golden):
+    g = golden("roc_cal_cos")
+    tar, non = g["tar"], g["non"]
+    pm, pf = O.compute_roc(tar, non)
+    assert np.array_equal(pm, g["roc_pmiss"]) and np.array_equal(pf, g["roc_pfa"])
+    for a, k in zip(O.pavx(g["pav_y"]), ("pav_ghat", "pav_width", "pav_height")):
+        assert np.array_equal(a, g[k])
+    for method in ("laplace", "raw"):
+        t, n = O.opt_loglr(tar, non, method)
+        assert np.array_equal(t, g["cal_tar_" + method]) and np.array_equal(n, g["cal_non_" + method])
+    for d in (512, 37):
+        assert np.allclose(O.cosine_scoring(g["cos%d_x1" % d], g["cos%d_x2" % d]), g["cos%d" % d], rtol=0, atol=1e-14)
+
+
+def test_pavx_is_host_code_and_bit_equal(golden):
+    from hyperion_amd.metrics import pavx
+
+    g = golden("roc_cal_cos")
+    ghat, width, height = pavx(g["pav_y"])
+    assert np.array_equal(ghat, g["pav_ghat"]) and np.array_equal(width, g["pav_width"])
+    assert np.array_equal(height, g["pav_height"])
+    assert np.all(np.diff(height) > 0) and width.sum() == len(g["pav_y"])
+    one = pavx([3.0])
+    assert one[0].tolist() == [3.0] and one[1].tolist() == [1]
+    with pytest.raises(AssertionError):
+        pavx([])
