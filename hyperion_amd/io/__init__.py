@@ -2,3 +2,4 @@
 from .ark import ArkDataWriter, RandomAccessArkDataReader  # noqa: F401
 from .factory import DataWriterFactory, RandomAccessDataReaderFactory  # noqa: F401
 from .h5 import H5DataWriter  # noqa: F401
+from .rw_specifiers import ArchiveType, RSpecifier, RSpecType, WSpecifier, WSpecType  # noqa: F401

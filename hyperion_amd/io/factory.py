@@ -3,44 +3,21 @@ hyperion/io/data_rw_factory.py:139-173): ark archives behind scp files, HDF5 fil
 over HDF5 files (the HDF5 side through the package's own reader); write specifiers
 `ark|h5[,scp][,f]:archive[,script]` -> writer objects (rw_specifiers.py:84-224,
 data_rw_factory.py:23-61)."""
-import re
-
 from .ark import ArkDataWriter, RandomAccessArkDataReader
 from .h5 import H5DataWriter, RandomAccessH5FileDataReader, RandomAccessH5ScriptDataReader
+from .rw_specifiers import ArchiveType, RSpecifier, RSpecType, WSpecifier
 
 
 class DataWriterFactory(object):
     @staticmethod
     def parse(wspecifier):
         """-> (kind 'ark' or 'h5', archive path, script path or None, flush)."""
-        fields = wspecifier.strip().split(":")
-        if len(fields) == 1:
-            assert len(fields[0]) > 0
-            return "h5", fields[0], None, False  # a bare path is an HDF5 archive
-        if len(fields) != 2:
-            raise ValueError("Two many fields (%d>2) in wspecifier %s" % (len(fields), wspecifier))
-        paths = fields[1].strip().split(",")
-        kind, archive, script, flush, cur = None, None, None, False, 0
-        for option in fields[0].strip().split(","):
-            if option in ("h5", "ark"):
-                assert kind is None, "Repeated h5, ark in wspecifier %s" % wspecifier
-                assert len(paths) > cur
-                kind, archive = option, paths[cur]
-                cur += 1
-            elif option == "scp":
-                assert script is None, "Repeated scp in wspecifier %s" % wspecifier
-                assert len(paths) > cur
-                script = paths[cur]
-                cur += 1
-            elif option == "f":
-                flush = True
-            elif option == "t":
-                raise NotImplementedError("text archives are not written")
-            elif option not in ("b", "nf", "p"):
-                raise ValueError("Wrong wspecifier options %s" % fields[0])
-        if kind is None:
-            raise ValueError("wspecifier %s names no ark or h5 archive" % wspecifier)
-        return kind, archive, script, flush
+        w = wspecifier if isinstance(wspecifier, WSpecifier) else WSpecifier.create(wspecifier)
+        if w.archive is None or w.archive_type not in (ArchiveType.H5, ArchiveType.ARK):
+            raise ValueError("wspecifier %s names no ark or h5 archive" % (wspecifier,))
+        if not w.binary:
+            raise NotImplementedError("text archives are not written")
+        return ("h5" if w.archive_type == ArchiveType.H5 else "ark"), w.archive, w.script, w.flush
 
     @staticmethod
     def create(wspecifier, compress=False, compression_method="auto", scp_sep=" "):
@@ -57,30 +34,14 @@ class DataWriterFactory(object):
 class RandomAccessDataReaderFactory(object):
     @staticmethod
     def parse(rspecifier):
-        """-> (kind, path, permissive) with kind 'scp' or 'ark' or 'h5'."""
-        fields = rspecifier.strip().split(":")
-        if len(fields) == 1:
-            assert len(fields[0]) > 0
-            return "h5", fields[0], False  # a bare path is an HDF5 archive (rw_specifiers.py:326-328)
-        if len(fields) != 2:
-            raise ValueError("Two many fields (%d>2) in wspecifier %s" % (len(fields), rspecifier))
-        kind, permissive = None, False
-        for option in fields[0].strip().split(","):
-            if option in ("scp", "ark", "h5"):
-                assert kind is None
-                kind = option
-            elif option == "p":
-                permissive = True
-            elif option not in ("o", "s", "cs", "bg"):
-                raise ValueError("Wrong wspecifier options %s" % fields[0])
-        assert kind is not None, "Wrong wspecifier options %s" % fields[0]
-        path = fields[1].strip()
-        if kind == "scp":
-            with open(path, "r") as f:
-                second = f.readline().strip().split(" ")[1]
-            if re.match(r".*\.h5(?:.[0-9]+:[0-9]+.)?$", second) is not None:
-                kind = "scp-h5"
-        return kind, path, permissive
+        """-> (kind, path, permissive) with kind 'scp' (Ark data), 'scp-h5', 'ark' or 'h5'."""
+        r = rspecifier if isinstance(rspecifier, RSpecifier) else RSpecifier.create(rspecifier)
+        if r.archive_type not in (ArchiveType.H5, ArchiveType.ARK):
+            raise ValueError("rspecifier %s: only ark and h5 data is read here" % (rspecifier,))
+        h5 = r.archive_type == ArchiveType.H5
+        if r.spec_type == RSpecType.SCRIPT:
+            return ("scp-h5" if h5 else "scp"), r.archive, r.permissive
+        return ("h5" if h5 else "ark"), r.archive, r.permissive
 
     @staticmethod
     def create(rspecifier, path_prefix=None, transform=None, scp_sep=" "):
