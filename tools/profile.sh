@@ -1,6 +1,8 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for bench.py on the GPU box.  Usage: tools/profile.sh <tag> [bench args]
 # Writes gpurun_out/prof_<tag>/{trace,fetch,write,sq}/ ; the summaries are copied to profiles/ by hand.
+# For the headline workload pass --no-asnorm-stage: the appended AS-norm stage launches the same score
+# kernel on small shapes, which would be averaged into the per-dispatch means of the counter passes.
 set -u
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
