@@ -31,6 +31,22 @@ class DataWriterFactory(object):
         return dict((k, kwargs[k]) for k in ("scp_sep", "compress", "compression_method") if k in kwargs)
 
 
+    compression_methods = ["auto", "speech-feat", "2byte-auto", "2byte-signed-integer", "1byte-auto",
+                           "1byte-unsigned-integer", "1byte-0-1", "speech-feat-t"]
+
+    @staticmethod
+    def add_class_args(parser, prefix=None):
+        """Writer options of the scripts (hyperion/io/data_rw_factory.py:63-77; the choices are those of
+        hyperion/utils/kaldi_matrix.py:244-253).  The reference nests them in a jsonargparse sub-parser
+        when a prefix is given; with plain argparse they are spelled `--<prefix>.<option>`."""
+        p1 = "--" if prefix is None else "--" + prefix + "."
+        parser.add_argument(p1 + "scp-sep", default=" ", help="scp file field separator")
+        parser.add_argument(p1 + "compress", default=False, action="store_true")
+        parser.add_argument(p1 + "compression-method", default="auto", choices=DataWriterFactory.compression_methods)
+
+    add_argparse_args = add_class_args
+
+
 class RandomAccessDataReaderFactory(object):
     @staticmethod
     def parse(rspecifier):
@@ -59,3 +75,18 @@ class RandomAccessDataReaderFactory(object):
     @staticmethod
     def filter_args(**kwargs):
         return dict((k, kwargs[k]) for k in ("scp_sep", "path_prefix") if k in kwargs)
+
+    @staticmethod
+    def add_class_args(parser, prefix=None):
+        """Reader options of the scripts (data_rw_factory.py:180-198); an option another helper has
+        already given the parser is left as it is, as there."""
+        import argparse
+
+        p1 = "--" if prefix is None else "--" + prefix + "."
+        try:
+            parser.add_argument(p1 + "scp-sep", default=" ", help="scp file field separator")
+        except argparse.ArgumentError:
+            pass
+        parser.add_argument(p1 + "path-prefix", default=None, help="scp file_path prefix")
+
+    add_argparse_args = add_class_args

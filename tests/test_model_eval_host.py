@@ -170,3 +170,25 @@ def test_pavx_is_host_code_and_bit_equal(golden):
     assert one[0].tolist() == [3.0] and one[1].tolist() == [1]
     with pytest.raises(AssertionError):
         pavx([])
+
+
+def test_io_factory_options_and_logger_levels():
+    import logging
+
+    from hyperion_amd import hyp_defs
+    from hyperion_amd.io import DataWriterFactory, RandomAccessDataReaderFactory
+
+    p = argparse.ArgumentParser()
+    DataWriterFactory.add_class_args(p)
+    RandomAccessDataReaderFactory.add_class_args(p)  # --scp-sep is already there: kept, not an error
+    ns = vars(p.parse_args(["--compress", "--compression-method", "2byte-auto", "--path-prefix", "/data"]))
+    assert DataWriterFactory.filter_args(**ns) == {"scp_sep": " ", "compress": True, "compression_method": "2byte-auto"}
+    assert RandomAccessDataReaderFactory.filter_args(**ns) == {"scp_sep": " ", "path_prefix": "/data"}
+    with pytest.raises(SystemExit):
+        p.parse_args(["--compression-method", "zip"])
+    assert hyp_defs.logging_levels == {0: logging.WARN, 1: logging.INFO, 2: logging.DEBUG, 3: 5}
+    assert hyp_defs.float_keras() == "float32"
+    hyp_defs.set_float_keras("float16")
+    assert hyp_defs.float_keras() == "float16"
+    hyp_defs.set_float_keras("float32")
+    assert callable(hyp_defs.config_logger)
