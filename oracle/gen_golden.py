@@ -480,6 +480,50 @@ def gen_roc_cal_cos():
     print("roc / calibration / cosine ok")
 
 
+def gen_math_helpers():
+    """Outputs of the small helpers of hyperion/utils/math.py:102-347 on seeded inputs."""
+    M = R.math
+    rng = np.random.RandomState(19)
+    d = 10
+    out = {}
+    r = rng.randn(7, d) * 5
+    out.update(r=r, softmax=M.softmax(r.copy()), softmax0=M.softmax(r.copy(), axis=0),
+               logsumexp=M.logsumexp(r.copy()), logsumexp0=M.logsumexp(r.copy(), axis=0))
+    xs = np.concatenate((rng.randn(20) * 30, [-150.0, -100.5, 0.0, 120.0]))
+    with np.errstate(over="ignore"):
+        out.update(xs=xs, logsigmoid=M.logsigmoid(xs.copy()), neglogsigmoid=M.neglogsigmoid(xs.copy()),
+                   sigmoid=M.sigmoid(xs.copy()))
+    spd = lambda: (lambda a: a @ a.T / d + np.eye(d))(rng.randn(d, d))  # noqa: E731
+    mu1, mu2, S1, S2 = rng.randn(d), rng.randn(d), spd(), spd()
+    out.update(mu1=mu1, mu2=mu2, S1=S1, S2=S2, fisher=M.fisher_ratio(mu1, S1, mu2, S2),
+               fisher_precs=M.fisher_ratio_with_precs(mu1, S1, mu2, S2))
+    A = spd()
+    for lower in (False, True):
+        t = "_l" if lower else "_u"
+        out["sym2vec" + t] = M.symmat2vec(A, lower=lower)
+        out["sym2vec_df" + t] = M.symmat2vec(A, lower=lower, diag_factor=0.5)
+        out["vec2sym" + t] = M.vec2symmat(out["sym2vec" + t], lower=lower)
+        out["vec2sym_df" + t] = M.vec2symmat(out["sym2vec_df" + t], lower=lower, diag_factor=2)
+        out["tri2vec" + t] = M.trimat2vec(np.tril(A) if lower else np.triu(A), lower=lower)
+        out["vec2tri" + t] = M.vec2trimat(out["tri2vec" + t], lower=lower)
+    import scipy.linalg as sla
+
+    S = 0.3 * spd()
+    F = spd()
+    out.update(A=A, vf_S=S, vf_F=F, vf=M.fullcov_varfloor(S.copy(), F.copy()),
+               vf_scalar=M.fullcov_varfloor(S.copy(), 0.7))
+    for lower in (False, True):
+        t = "_l" if lower else "_u"
+        cF, cS = sla.cholesky(F, lower=lower), sla.cholesky(S, lower=lower)
+        out["vf_chol" + t] = M.fullcov_varfloor(S.copy(), cF.copy(), F_is_chol=True, lower=lower)
+        out["vf_from_chol" + t] = M.fullcov_varfloor_from_cholS(cS.copy(), cF.copy(), lower=lower)
+        out["vf_from_chol_scalar" + t] = M.fullcov_varfloor_from_cholS(cS.copy(), np.sqrt(0.7), lower=lower)
+    ids = rng.randint(0, 6, 15)
+    out.update(ids=ids, onehot=M.int2onehot(ids), onehot9=M.int2onehot(ids, 9))
+    np.savez_compressed(os.path.join(OUT, "math_helpers.npz"), **out)
+    print("math helpers ok")
+
+
 def gen_training_stats():
     """Whitening / LDA fits and PLDA sufficient statistics of the reference on labelled vectors
     (hyperion/transforms/cent_whiten.py:35-62, sb_sw.py:25-50, lda.py:36-68,
@@ -825,6 +869,7 @@ def gen_diarization():
 
 if __name__ == "__main__":
     gen_model_eval()
+    gen_math_helpers()
     gen_roc_cal_cos()
     gen_ahc_levels()
     os.makedirs(OUT, exist_ok=True)
