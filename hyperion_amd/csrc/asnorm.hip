@@ -295,6 +295,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float* __re
 constexpr int TR_THREADS = 256, TR_WAVES = TR_THREADS / 64;
 constexpr int TR_CAND = 1024;     // the bracket is narrow once it holds at most this many keys
 constexpr int TR_STAGE = 8192;    // longest list staged in LDS before it is written (entries)
+constexpr int TR_ORDER = 2048;    // longest list that leaves ordered by LDS bank class
 constexpr int TR_MAX_ITEMS = 160;
 constexpr int TR_MAX_NC = TR_MAX_ITEMS * TR_THREADS;
 
@@ -441,6 +442,9 @@ __global__ __launch_bounds__(TR_THREADS) void topk_rows_reg_kernel(const float* 
     __shared__ unsigned short cand_idx[2 * TK_CAND];
     __shared__ unsigned char cand_above[2 * TK_CAND];
     __shared__ __attribute__((aligned(16))) unsigned short stage[TR_STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned short ordered[TR_ORDER];
+    __shared__ unsigned short bank_cnt[8][32];
+    __shared__ unsigned short bank_start[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row = blockIdx.x;
     int par = 0;
@@ -674,8 +678,49 @@ __global__ __launch_bounds__(TR_THREADS) void topk_rows_reg_kernel(const float* 
     }
     if (staged) {
         __syncthreads();
+        const unsigned short* src_list = stage;
+        if (k <= TR_ORDER) {
+            // bank_order: members by (index mod 32), the class of LDS banks their values fall into in
+            // the gather, then rotated by a (row mod 32)-th of the list, so that the 32 lists a half
+            // wave walks in step are in different classes most of the time.  Stable within a class:
+            // thread (part, b) takes the members of class b in the part-th eighth of the staged list.
+            const int b = tid & 31, part = tid >> 5, per = (k + 7) >> 3;
+            const int p0 = part * per, p1 = p0 + per < k ? p0 + per : k;
+            int mine = 0;
+            for (int p = p0; p < p1; ++p) mine += (stage[p] & 31) == b ? 1 : 0;
+            bank_cnt[part][b] = (unsigned short)mine;
+            __syncthreads();
+            if (tid < 32) {  // first member of every class: exclusive scan of the class totals
+                int tot = 0;
+#pragma unroll
+                for (int q2 = 0; q2 < 8; ++q2) tot += bank_cnt[q2][tid];
+                int incl = tot;
+#pragma unroll
+                for (int off = 1; off < 32; off <<= 1) {
+                    const int v = __shfl_up(incl, off, 64);
+                    if (tid >= off) incl += v;
+                }
+                bank_start[tid] = (unsigned short)(incl - tot);
+            }
+            __syncthreads();
+            int at = bank_start[b];
+            for (int q2 = 0; q2 < part; ++q2) at += bank_cnt[q2][b];
+            const int rot = (int)(((row & 31) * k) >> 5);
+            for (int p = p0; p < p1; ++p) {
+                const unsigned short c = stage[p];
+                if ((c & 31) == b) {
+                    int dst = at - rot;
+                    if (dst < 0) dst += k;
+                    ordered[dst] = c;
+                    ++at;
+                }
+            }
+            if (tid < 8 && k + tid < 8 * groups) ordered[k + tid] = 0;  // tail of the last group
+            __syncthreads();
+            src_list = ordered;
+        }
         for (int g = tid; g < groups; g += TR_THREADS)
-            reinterpret_cast<uint4*>(idx8)[(int64_t)g * ldi + row] = reinterpret_cast<const uint4*>(stage)[g];
+            reinterpret_cast<uint4*>(idx8)[(int64_t)g * ldi + row] = reinterpret_cast<const uint4*>(src_list)[g];
     }
 }
 
@@ -835,6 +880,235 @@ __global__ __launch_bounds__(GS_THREADS) void gather_stats_kernel(
         }
     }
 }
+
+// ---- unmasked, LDS-resident gather (the adaptive S-norm hot loop) -----------------------------------
+// Measured on MI355X (tools/probes/gather_rate.hip, lds_rate.hip): the walk is bound by instruction
+// issue, not by LDS bytes -- a SIMD spends about 10 clocks on a ds_read_b64, 3 on a plain f32 add or
+// fma, 4.5 on an integer multiply-add and 7.7 on a packed f32 instruction (more than two plain ones),
+// and these add up; a dependent index load per eight entries stalls the wave unless several are in
+// flight; random lists cost 3.5 LDS cycles per half wave instead of 1.  Hence:
+//   * the rows are stored in LDS minus a per-row pivot (an estimate of the row's mean), so the loop
+//     has no subtraction: one v_mad_u32_u16 (16-bit entry -> byte address), one LDS read, and a plain
+//     add + fma per value, written as single instructions so that they are not packed;
+//   * every lane keeps GP_RING 16-byte index loads in flight over the flattened (list, group)
+//     sequence of its lists;
+//   * the lists arrive ordered by LDS bank class and rotated by lane (see bank_order in the top-k
+//     kernel), which removes most bank conflicts without any coordination between lists.
+// With a per-row pivot the variance is s2/k - (s1/k)^2 with s2/k up to GP_AMP times the variance; for
+// the few (row, list) pairs beyond that (a selection far out in the tail of its row, or constant)
+// the lane walks the list again around the list's own first member, which is what the general kernel
+// above does for every pair.
+constexpr int GP_RING = 4;
+constexpr float GP_AMP = 16.f;
+constexpr int GP_SCRATCH_FLOATS = 80;  // per-wave partial sums of the pivot estimate (R x 16) + pad
+
+__device__ unsigned long long g_gather_redo;  // (row, list) pairs redone around a list pivot (diagnostic)
+
+template <int R>
+__device__ __forceinline__ typename VecR<R>::type lds_vec(const char* xb, unsigned addr) {
+    return *reinterpret_cast<const typename VecR<R>::type*>(xb + addr);
+}
+
+// byte address of 16-bit entry (low or high half of w) of an LDS array of R floats per entry
+template <int R, int HI>
+__device__ __forceinline__ unsigned entry_addr(unsigned w) {
+    unsigned a;
+    if (HI) asm("v_mad_u32_u16 %0, %1, %2, 0 op_sel:[1,0,0,0]" : "=v"(a) : "v"(w), "n"(4 * R));
+    else asm("v_mad_u32_u16 %0, %1, %2, 0" : "=v"(a) : "v"(w), "n"(4 * R));
+    return a;
+}
+
+__device__ __forceinline__ void moment_step(float& s1, float& s2, float v) {
+    asm("v_add_f32 %0, %1, %0" : "+v"(s1) : "v"(v));
+    asm("v_fma_f32 %0, %1, %1, %0" : "+v"(s2) : "v"(v));
+}
+
+// The general walk of one list for the R rows in LDS, around the list's first member (fp32 shifted
+// moments: exact zero variance for a constant selection).  Cold path of gather_pivot_kernel.
+template <int R>
+struct ShiftedMoments {
+    float piv[R], s1[R], s2[R];
+};
+
+// Returned by value (registers): taking the caller's accumulators by reference would put them in
+// scratch memory for the whole hot loop.
+template <int R>
+__device__ __noinline__ ShiftedMoments<R> list_moments_shifted(const char* xb, const uint4* lp, int64_t ldi, int k) {
+    typedef typename VecR<R>::type vec_t;
+    ShiftedMoments<R> m;
+    unpack<R>(*reinterpret_cast<const vec_t*>(xb + (size_t)(lp[0].x & 0xffffu) * (4 * R)), m.piv);
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) m.s1[rr] = m.s2[rr] = 0.f;
+    for (int j = 0; j < k; ++j) {
+        const uint4 pk = lp[(int64_t)(j >> 3) * ldi];
+        const unsigned w = (j & 4) ? ((j & 2) ? pk.w : pk.z) : ((j & 2) ? pk.y : pk.x);
+        const unsigned c = (w >> (16 * (j & 1))) & 0xffffu;
+        float v[R];
+        unpack<R>(*reinterpret_cast<const vec_t*>(xb + (size_t)c * (4 * R)), v);
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const float d = v[rr] - m.piv[rr];
+            m.s1[rr] += d;
+            m.s2[rr] = fmaf(d, d, m.s2[rr]);
+        }
+    }
+    return m;
+}
+
+template <int R>
+__global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
+    const float* __restrict__ X, int64_t ldx, int64_t n_rows, int nc, const uint16_t* __restrict__ idx8,
+    int64_t ldi, int k, int64_t Q, int64_t q_per_block, float floor_, float* __restrict__ mean,
+    float* __restrict__ istd, int64_t ldo) {
+    extern __shared__ __attribute__((aligned(16))) float xr[];
+    float* red = xr + (size_t)nc * R;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * R;
+    // pivot of a row: mean of its first min(nc, 1024) entries (the cohort order carries no meaning)
+    float rowpiv[R];
+    {
+        const int ns = nc < GS_THREADS ? nc : GS_THREADS;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            float v = (r0 + rr < n_rows && tid < ns) ? X[(r0 + rr) * ldx + tid] : 0.f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0) red[rr * 16 + wave] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < GS_THREADS / 64; ++w) s += red[rr * 16 + w];
+            rowpiv[rr] = s / (float)ns;
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+        const bool live = r0 + rr < n_rows;
+        const float* src = X + (r0 + rr) * ldx;
+        for (int c = tid; c < nc; c += GS_THREADS)
+            xr[c * R + rr] = live ? __builtin_nontemporal_load(src + c) - rowpiv[rr] : 0.f;
+    }
+    __syncthreads();
+    const char* xb = reinterpret_cast<const char*>(xr);
+
+    const int G = (k + 7) >> 3, krem = k & 7;
+    const int64_t q0 = (int64_t)blockIdx.y * q_per_block;
+    const int64_t q1 = (q0 + q_per_block < Q) ? q0 + q_per_block : Q;
+    if (q0 >= q1) return;
+    // Entries past the end of a list (the last group holds krem of them) are redirected to a slot
+    // of zeros behind the rows: a zero adds nothing to either moment.
+    if (tid < R) xr[(size_t)nc * R + tid] = 0.f;  // `red` is no longer needed
+    __syncthreads();
+    unsigned keep[4], fill[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const bool lo_ok = krem == 0 || 2 * w < krem, hi_ok = krem == 0 || 2 * w + 1 < krem;
+        keep[w] = (lo_ok ? 0xffffu : 0u) | (hi_ok ? 0xffff0000u : 0u);
+        fill[w] = (lo_ok ? 0u : (unsigned)nc) | (hi_ok ? 0u : (unsigned)nc << 16);
+    }
+    // lists per lane (the last may be missing) and index groups per lane: the same in every lane
+    const int nl = __builtin_amdgcn_readfirstlane((int)((q1 - q0 + GS_THREADS - 1) / GS_THREADS));
+    const int n = nl * G;  // the launcher keeps this below 2^31
+    const uint4* base = reinterpret_cast<const uint4*>(idx8);
+    // A lane without a list in the last round walks the block's last list and stores nothing.
+    // The index loads of a lane form one stream over (list, group); its pointer moves by ldi inside
+    // a list and by `hop` (plus `hop_fix` into the last round) from the end of one list to the next.
+    const int64_t q_first = q0 + tid < q1 ? q0 + tid : q1 - 1;
+    const int64_t q_last_want = q0 + tid + (int64_t)(nl - 1) * GS_THREADS;
+    const int64_t hop = (int64_t)GS_THREADS - (int64_t)(G - 1) * ldi;
+    const int64_t hop_fix = (nl >= 2 && q_last_want >= q1) ? (q1 - 1) - q_last_want : 0;  // <= 0
+    const uint4* p_ld = base + q_first;
+    int l_ld = 0, g_ld = 0;  // uniform
+    uint4 ring[GP_RING];
+#define HYPMI_NEXT_LOAD(dst)                                         \
+    {                                                                \
+        dst = *p_ld;                                                 \
+        if (++g_ld == G) {                                           \
+            g_ld = 0;                                                \
+            ++l_ld;                                                  \
+            p_ld += hop;                                             \
+            if (l_ld == nl - 1) p_ld += hop_fix;                     \
+        } else {                                                     \
+            p_ld += ldi;                                             \
+        }                                                            \
+    }
+#pragma unroll
+    for (int d = 0; d < GP_RING; ++d)
+        if (d < n) HYPMI_NEXT_LOAD(ring[d])
+
+    float s1[R], s2[R];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) s1[rr] = s2[rr] = 0.f;
+    auto add = [&](unsigned addr) {
+        float v[R];
+        unpack<R>(lds_vec<R>(xb, addr), v);
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) moment_step(s1[rr], s2[rr], v[rr]);
+    };
+    int g = 0, l = 0;
+    const float inv_k = 1.0f / (float)k;
+    for (int i = 0; i < n; i += GP_RING) {
+#pragma unroll
+        for (int d = 0; d < GP_RING; ++d) {
+            if (i + d < n) {
+                uint4 pk = ring[d];
+                if (i + d + GP_RING < n) HYPMI_NEXT_LOAD(ring[d])
+                if (krem != 0 && g == G - 1) {
+                    pk.x = (pk.x & keep[0]) | fill[0];
+                    pk.y = (pk.y & keep[1]) | fill[1];
+                    pk.z = (pk.z & keep[2]) | fill[2];
+                    pk.w = (pk.w & keep[3]) | fill[3];
+                }
+                add(entry_addr<R, 0>(pk.x)); add(entry_addr<R, 1>(pk.x));
+                add(entry_addr<R, 0>(pk.y)); add(entry_addr<R, 1>(pk.y));
+                add(entry_addr<R, 0>(pk.z)); add(entry_addr<R, 1>(pk.z));
+                add(entry_addr<R, 0>(pk.w)); add(entry_addr<R, 1>(pk.w));
+                if (++g == G) {
+                    // The sums carry fp32 rounding (about 1e-6 relative); so does this arithmetic.
+                    const int64_t q = q0 + tid + (int64_t)l * GS_THREADS;
+                    const bool live_q = q < q1;
+                    float lp[R];
+                    bool redo = false;
+#pragma unroll
+                    for (int rr = 0; rr < R; ++rr) {
+                        lp[rr] = 0.f;
+                        const float md = s1[rr] * inv_k, ms = s2[rr] * inv_k;
+                        redo |= fmaf(-md, md, ms) * GP_AMP < ms;  // false for NaN: those stay NaN
+                    }
+                    if (redo && live_q) {
+                        const ShiftedMoments<R> m = list_moments_shifted<R>(xb, base + q, ldi, k);
+#pragma unroll
+                        for (int rr = 0; rr < R; ++rr) {
+                            lp[rr] = m.piv[rr];
+                            s1[rr] = m.s1[rr];
+                            s2[rr] = m.s2[rr];
+                        }
+                        atomicAdd(&g_gather_redo, 1ull);
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < R; ++rr) {
+                        const float md = s1[rr] * inv_k;
+                        const float var = fmaf(-md, md, s2[rr] * inv_k);
+                        float sd = sqrtf(var > 0.f ? var : (var == var ? 0.f : var));
+                        if (sd < floor_) sd = floor_;
+                        if (live_q && r0 + rr < n_rows) {
+                            mean[(r0 + rr) * ldo + q] = (rowpiv[rr] + lp[rr]) + md;
+                            istd[(r0 + rr) * ldo + q] = 1.0f / sd;
+                        }
+                        s1[rr] = s2[rr] = 0.f;
+                    }
+                    g = 0;
+                    ++l;
+                }
+            }
+        }
+    }
+}
+
+#undef HYPMI_NEXT_LOAD
 
 // out[e, t] = ((S - mz[e,t]) * iz[e,t] + (S - mt[t,e]) * it[t,e]) / sqrt(2); the T-part statistics
 // arrive transposed and go through a 32 x 33 LDS tile.
@@ -1028,6 +1302,18 @@ extern "C" int hypmi_topk_rows(const float* A, int64_t n_rows, int nc, int64_t l
 }
 
 namespace {
+// One workgroup walks all lists for its rows unless there are too few row groups to fill the chip, in
+// which case the lists are split over blockIdx.y (every block of lists reloads the rows, so blocks
+// are kept as large as that allows).
+inline void gather_grid(int64_t groups, int64_t n_lists, int64_t* chunks_out, int64_t* q_per_block_out) {
+    int64_t chunks = 1;
+    while (groups * chunks < 1024 && (n_lists + chunks - 1) / chunks > 4 * GS_THREADS) chunks *= 2;
+    if (chunks > 65535) chunks = 65535;
+    const int64_t q_per_block = round_up((n_lists + chunks - 1) / chunks, GS_THREADS);
+    *chunks_out = (n_lists + q_per_block - 1) / q_per_block;
+    *q_per_block_out = q_per_block;
+}
+
 template <int R, bool MASK, bool IN_LDS = true>
 int launch_gather(const float* X, int64_t n_rows, int nc, int64_t ldx, const unsigned char* mask,
                   int64_t ldm, const uint16_t* idx8, int64_t ldi, int k, int64_t n_lists, float std_floor,
@@ -1039,24 +1325,35 @@ int launch_gather(const float* X, int64_t n_rows, int nc, int64_t ldx, const uns
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
     const int64_t groups = (n_rows + R - 1) / R;
     HYPMI_REQUIRE(groups <= 0x7fffffffLL, "gather_stats: too many rows");
-    // One workgroup walks all lists for its rows unless there are too few row groups to fill the chip,
-    // in which case the lists are split over blockIdx.y.  Measured at 10k rows x 65536 lists x 300 of
-    // 20000 (23.3 ms, 13.7 elements/clk/CU): splitting the lists so that a block of them stays in L2 is
-    // slower with every doubling (24.6 ms at 4 blocks ... 45 ms at 64: each block reloads the rows);
-    // six index loads in flight per lane instead of two change nothing; an index stream confined to
-    // 1024 lists (all cache hits) gains 5 %; one VALU instruction less per entry gains nothing; lists
-    // without any bank conflict (all entries equal) take 19.0 ms = 7.6 clocks per ds_read_b64 of a
-    // wave.  The walk is bound by the LDS itself: a random 8-byte gather per lane sustains about
-    // 60 bytes per clock and CU, and four-row workgroups (one 16-byte read per entry, possible for
-    // cohorts up to 10 240) are only 1.17 times faster per element.
-    int64_t chunks = 1;
-    while (groups * chunks < 1024 && (n_lists + chunks - 1) / chunks > 4 * GS_THREADS) chunks *= 2;
-    if (chunks > 65535) chunks = 65535;
-    const int64_t q_per_block = round_up((n_lists + chunks - 1) / chunks, GS_THREADS);
-    chunks = (n_lists + q_per_block - 1) / q_per_block;
+    int64_t chunks, q_per_block;
+    gather_grid(groups, n_lists, &chunks, &q_per_block);
     hipLaunchKernelGGL((gather_stats_kernel<R, MASK, IN_LDS>), dim3((unsigned)groups, (unsigned)chunks),
                        dim3(GS_THREADS), lds_need, stream, X, ldx, n_rows, mask, ldm, nc, idx8, ldi, k,
                        n_lists, q_per_block, std_floor, mean, istd, ldo);
+    HYPMI_HIP(hipGetLastError());
+    return HYPMI_OK;
+}
+
+inline int64_t pivot_lds_bytes(int nc, int R) {
+    return round_up(((int64_t)nc * R + GP_SCRATCH_FLOATS) * 4, 16);
+}
+
+template <int R>
+int launch_gather_pivot(const float* X, int64_t n_rows, int nc, int64_t ldx, const uint16_t* idx8, int64_t ldi,
+                        int k, int64_t n_lists, float std_floor, float* mean, float* istd, int64_t ldo,
+                        hipStream_t stream) {
+    const int64_t lds_need = pivot_lds_bytes(nc, R);
+    if (lds_need > 48 * 1024)
+        HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_pivot_kernel<R>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
+    const int64_t groups = (n_rows + R - 1) / R;
+    HYPMI_REQUIRE(groups <= 0x7fffffffLL, "gather_stats: too many rows");
+    int64_t chunks, q_per_block;
+    gather_grid(groups, n_lists, &chunks, &q_per_block);
+    HYPMI_REQUIRE((q_per_block / GS_THREADS) * ((k + 7) / 8) < 0x7fffffffLL, "gather_stats: lists too long");
+    hipLaunchKernelGGL((gather_pivot_kernel<R>), dim3((unsigned)groups, (unsigned)chunks), dim3(GS_THREADS),
+                       lds_need, stream, X, ldx, n_rows, nc, idx8, ldi, k, n_lists, q_per_block, std_floor, mean,
+                       istd, ldo);
     HYPMI_HIP(hipGetLastError());
     return HYPMI_OK;
 }
@@ -1080,18 +1377,44 @@ extern "C" int hypmi_gather_stats(const float* X, int64_t n_rows, int nc, int64_
                     : launch_gather<1, false, false>(X, n_rows, nc, ldx, mask, ldm, idx_t, ldi, k, n_lists,
                                                      std_floor, mean, istd, ldo, stream);
     // as many rows per workgroup as LDS holds (each index fetched is reused for all of them)
+    if (!mask) {
+        int R = 1;
+        if (pivot_lds_bytes(nc, 4) <= MAX_LDS_BYTES && n_rows >= 4) R = 4;
+        else if (pivot_lds_bytes(nc, 2) <= MAX_LDS_BYTES && n_rows >= 2) R = 2;
+        if (pivot_lds_bytes(nc, R) <= MAX_LDS_BYTES) {
+            if (R == 4)
+                return launch_gather_pivot<4>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, mean, istd, ldo,
+                                              stream);
+            if (R == 2)
+                return launch_gather_pivot<2>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, mean, istd, ldo,
+                                              stream);
+            return launch_gather_pivot<1>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, mean, istd, ldo,
+                                          stream);
+        }
+        return launch_gather<1, false>(X, n_rows, nc, ldx, mask, ldm, idx_t, ldi, k, n_lists, std_floor, mean,
+                                       istd, ldo, stream);
+    }
     int R = 1;
     if (4 * per_row <= MAX_LDS_BYTES && n_rows >= 4) R = 4;
     else if (2 * per_row <= MAX_LDS_BYTES && n_rows >= 2) R = 2;
-#define HYPMI_GS(RR)                                                                                  \
-    return mask ? launch_gather<RR, true>(X, n_rows, nc, ldx, mask, ldm, idx_t, ldi, k, n_lists,      \
-                                          std_floor, mean, istd, ldo, stream)                         \
-                : launch_gather<RR, false>(X, n_rows, nc, ldx, mask, ldm, idx_t, ldi, k, n_lists,     \
-                                           std_floor, mean, istd, ldo, stream)
-    if (R == 4) { HYPMI_GS(4); }
-    if (R == 2) { HYPMI_GS(2); }
-    HYPMI_GS(1);
-#undef HYPMI_GS
+    if (R == 4)
+        return launch_gather<4, true>(X, n_rows, nc, ldx, mask, ldm, idx_t, ldi, k, n_lists, std_floor, mean, istd,
+                                      ldo, stream);
+    if (R == 2)
+        return launch_gather<2, true>(X, n_rows, nc, ldx, mask, ldm, idx_t, ldi, k, n_lists, std_floor, mean, istd,
+                                      ldo, stream);
+    return launch_gather<1, true>(X, n_rows, nc, ldx, mask, ldm, idx_t, ldi, k, n_lists, std_floor, mean, istd, ldo,
+                                  stream);
+}
+
+extern "C" int hypmi_gather_redo_count(unsigned long long* count, int reset) {
+    HYPMI_REQUIRE(count, "gather_redo_count: null pointer");
+    HYPMI_HIP(hipMemcpyFromSymbol(count, HIP_SYMBOL(g_gather_redo), sizeof(unsigned long long)));
+    if (reset) {
+        const unsigned long long zero = 0;
+        HYPMI_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gather_redo), &zero, sizeof(zero)));
+    }
+    return HYPMI_OK;
 }
 
 extern "C" int hypmi_asnorm_apply(const float* S, int64_t lds_, int64_t ne, int64_t nt, const float* mz,

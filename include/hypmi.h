@@ -206,9 +206,13 @@ int hypmi_scatter_block(const float* blk, int64_t ldb, const int32_t* ri, int64_
 /* ---- score normalisation (hyperion/score_norm) ---------------------------------------------- */
 
 /* Per-row top-k over the cohort: for every row of A[n_rows x nc] (nc <= 65536) the cohort indices
- * ranked discard .. discard+k-1 by descending score, in ascending index order.  Replaces
- * np.argsort + flip + slice (adapt_s_norm.py:42-44, 65-67); ties at a boundary are resolved towards
- * the lower cohort index (numpy leaves that order unspecified).
+ * ranked discard .. discard+k-1 by descending score.  Replaces np.argsort + flip + slice
+ * (adapt_s_norm.py:42-44, 65-67); ties at a boundary are resolved towards the lower cohort index
+ * (numpy leaves that order unspecified).  The ORDER of the members inside a list is not their rank
+ * (the statistics taken over a list do not depend on it): lists of up to 2048 members leave ordered
+ * by (index mod 32) and rotated by (row mod 32), which spreads the lanes of a half wave of
+ * hypmi_gather_stats over the LDS banks; longer ones leave in ascending index order.  The same
+ * input always gives the same list.
  * List layout (uint16, groups of eight so that one 16-byte load fetches eight entries of a list):
  *   entry j of the list of row q is idx[((j >> 3) * ldi + q) * 8 + (j & 7)],  ldi >= n_rows,
  * hypmi_topk_list_bytes(k, ldi) bytes in all, 16-byte aligned.
@@ -246,10 +250,17 @@ int hypmi_topk_rows(const float* A, int64_t n_rows, int nc, int64_t lda, int k, 
  * X[n_rows x nc] and list q (layout above): mean[r,q] and istd[r,q] = 1 / max(std, std_floor) of
  * X[r, list_q] (population std).  With mask (uint8 [n_rows x nc], 0 = masked, X already zeroed
  * there) the moments are divided by the unmasked fraction as adapt_s_norm.py:54-60 does.
- * The cohort row must fit in LDS (nc <= 40960 without mask). */
+ * Rows of up to 40 880 cohort members (unmasked) are gathered from LDS, longer ones from global
+ * memory, an order of magnitude slower. */
 int hypmi_gather_stats(const float* X, int64_t n_rows, int nc, int64_t ldx, const unsigned char* mask,
                        int64_t ldm, const uint16_t* idx, int64_t ldi, int k, int64_t n_lists,
                        float std_floor, float* mean, float* istd, int64_t ldo, void* stream);
+
+/* Diagnostic: the number of (row, list) pairs hypmi_gather_stats has recomputed around the list's
+ * own first member since the last reset, because their selection lies so far from the row's mean
+ * that the one-pass variance about the row pivot would lose more than four bits (on the current
+ * device; synchronises with it).  No counterpart in the reference. */
+int hypmi_gather_redo_count(unsigned long long* count, int reset);
 
 /* out[e,t] = ((S - mz[e,t]) iz[e,t] + (S - mt[t,e]) it[t,e]) / sqrt(2)  (adapt_s_norm.py:63,86,88). */
 int hypmi_asnorm_apply(const float* S, int64_t lds, int64_t ne, int64_t nt, const float* mz,

@@ -72,6 +72,11 @@ for rep in range(a.reps):
                                           engine._ptr(iz), ldz, engine._ptr(mt), engine._ptr(it), ldt,
                                           engine._ptr(out), out.stride(0), engine.stream_ptr()))
     t.run("apply", app)
+import ctypes  # noqa: E402
+
+redo = ctypes.c_ulonglong(0)
+_lib.check(lib.hypmi_gather_redo_count(ctypes.byref(redo), 1))
+print("gather pairs redone around a list pivot: %d of %d (all repetitions)" % (redo.value, 2 * a.reps * a.ne * a.nt))
 tot = 0.0
 for k, v in t.acc.items():
     print("%-22s %10.3f ms" % (k, v[-1]))
