@@ -904,17 +904,37 @@ constexpr int GP_SCRATCH_FLOATS = 80;  // per-wave partial sums of the pivot est
 
 __device__ unsigned long long g_gather_redo;  // (row, list) pairs redone around a list pivot (diagnostic)
 
+// An LDS read at a byte address of the LDS address space (not relative to an array: the address
+// computation already contains the array's base, so that it costs no instruction of its own).
 template <int R>
-__device__ __forceinline__ typename VecR<R>::type lds_vec(const char* xb, unsigned addr) {
-    return *reinterpret_cast<const typename VecR<R>::type*>(xb + addr);
+struct LdsVec {
+    typedef float type __attribute__((ext_vector_type(R)));
+};
+template <>
+struct LdsVec<1> { typedef float type; };
+
+template <int R>
+__device__ __forceinline__ typename LdsVec<R>::type lds_vec(unsigned addr) {
+    typedef __attribute__((address_space(3))) const typename LdsVec<R>::type lds_t;
+    return *reinterpret_cast<lds_t*>(addr);
 }
 
-// byte address of 16-bit entry (low or high half of w) of an LDS array of R floats per entry
+template <int R>
+__device__ __forceinline__ float lds_vec_elem(const typename LdsVec<R>::type& v, int rr) { return v[rr]; }
+template <>
+__device__ __forceinline__ float lds_vec_elem<1>(const float& v, int) { return v; }
+
+__device__ __forceinline__ unsigned lds_address(const void* p) {
+    return (unsigned)reinterpret_cast<size_t>((__attribute__((address_space(3))) const void*)p);
+}
+
+// LDS byte address of 16-bit entry (low or high half of w) of an array of R floats per entry at
+// LDS address `base`: one instruction
 template <int R, int HI>
-__device__ __forceinline__ unsigned entry_addr(unsigned w) {
+__device__ __forceinline__ unsigned entry_addr(unsigned w, unsigned base) {
     unsigned a;
-    if (HI) asm("v_mad_u32_u16 %0, %1, %2, 0 op_sel:[1,0,0,0]" : "=v"(a) : "v"(w), "n"(4 * R));
-    else asm("v_mad_u32_u16 %0, %1, %2, 0" : "=v"(a) : "v"(w), "n"(4 * R));
+    if (HI) asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(a) : "v"(w), "n"(4 * R), "s"(base));
+    else asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(a) : "v"(w), "n"(4 * R), "s"(base));
     return a;
 }
 
@@ -993,6 +1013,7 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
     }
     __syncthreads();
     const char* xb = reinterpret_cast<const char*>(xr);
+    const unsigned xbase = __builtin_amdgcn_readfirstlane(lds_address(xr));
 
     const int G = (k + 7) >> 3, krem = k & 7;
     const int64_t q0 = (int64_t)blockIdx.y * q_per_block;
@@ -1042,14 +1063,8 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
     float s1[R], s2[R];
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) s1[rr] = s2[rr] = 0.f;
-    auto add = [&](unsigned addr) {
-        float v[R];
-        unpack<R>(lds_vec<R>(xb, addr), v);
-#pragma unroll
-        for (int rr = 0; rr < R; ++rr) moment_step(s1[rr], s2[rr], v[rr]);
-    };
     int g = 0, l = 0;
-    const float inv_k = 1.0f / (float)k;
+    const float inv_k = 1.0f / (float)k, floor2 = floor_ * floor_, inv_floor = 1.0f / floor_;
     for (int i = 0; i < n; i += GP_RING) {
 #pragma unroll
         for (int d = 0; d < GP_RING; ++d) {
@@ -1062,10 +1077,22 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
                     pk.z = (pk.z & keep[2]) | fill[2];
                     pk.w = (pk.w & keep[3]) | fill[3];
                 }
-                add(entry_addr<R, 0>(pk.x)); add(entry_addr<R, 1>(pk.x));
-                add(entry_addr<R, 0>(pk.y)); add(entry_addr<R, 1>(pk.y));
-                add(entry_addr<R, 0>(pk.z)); add(entry_addr<R, 1>(pk.z));
-                add(entry_addr<R, 0>(pk.w)); add(entry_addr<R, 1>(pk.w));
+                // addresses, then all eight reads, then the arithmetic (the fences keep the reads of a
+                // group in flight together instead of one wait per read)
+                unsigned a[8];
+                a[0] = entry_addr<R, 0>(pk.x, xbase); a[1] = entry_addr<R, 1>(pk.x, xbase);
+                a[2] = entry_addr<R, 0>(pk.y, xbase); a[3] = entry_addr<R, 1>(pk.y, xbase);
+                a[4] = entry_addr<R, 0>(pk.z, xbase); a[5] = entry_addr<R, 1>(pk.z, xbase);
+                a[6] = entry_addr<R, 0>(pk.w, xbase); a[7] = entry_addr<R, 1>(pk.w, xbase);
+                __builtin_amdgcn_sched_barrier(0);
+                typename LdsVec<R>::type val[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) val[e] = lds_vec<R>(a[e]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+#pragma unroll
+                    for (int rr = 0; rr < R; ++rr) moment_step(s1[rr], s2[rr], lds_vec_elem<R>(val[e], rr));
                 if (++g == G) {
                     // The sums carry fp32 rounding (about 1e-6 relative); so does this arithmetic.
                     const int64_t q = q0 + tid + (int64_t)l * GS_THREADS;
@@ -1091,12 +1118,13 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
 #pragma unroll
                     for (int rr = 0; rr < R; ++rr) {
                         const float md = s1[rr] * inv_k;
-                        const float var = fmaf(-md, md, s2[rr] * inv_k);
-                        float sd = sqrtf(var > 0.f ? var : (var == var ? 0.f : var));
-                        if (sd < floor_) sd = floor_;
+                        float var = fmaf(-md, md, s2[rr] * inv_k);
+                        var = var > 0.f ? var : (var == var ? 0.f : var);  // NaN stays NaN
+                        // 1 / max(sqrt(var), floor): v_rsq_f32 is good to one unit in the last place
+                        const float is = var < floor2 ? inv_floor : __builtin_amdgcn_rsqf(var);
                         if (live_q && r0 + rr < n_rows) {
                             mean[(r0 + rr) * ldo + q] = (rowpiv[rr] + lp[rr]) + md;
-                            istd[(r0 + rr) * ldo + q] = 1.0f / sd;
+                            istd[(r0 + rr) * ldo + q] = is;
                         }
                         s1[rr] = s2[rr] = 0.f;
                     }
