@@ -1,17 +1,20 @@
 #!/usr/bin/env python
 """Benchmark of the PLDA back-end scoring hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload chain_splda_100k|...]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload asnorm_10k_1m|...]
 
-One "step" = one pass of the hot path over one batch of synthetic x-vectors that are already
-resident in HBM: embedding prologue (pre-processing chain + PLDA projection) for the enrol and the
-test side, conversion of the packed rows to scaled fp16 pairs, then the full trial score matrix
-(kept on the device).  With N > 1 every rank scores the
-same enrol set against its own shard of test vectors (row-wise test sharding, no data-path
-collective): per-GPU work is fixed, so scaling is "weak" and the reported value is the number of
-scores all ranks produced divided by the slowest rank's time.
+Default workload: the configuration the headline metric is quoted on -- SPLDA scores with adaptive
+S-norm, 10 000 enrolment models x 1 000 000 test x-vectors per GPU against a 20 000-member cohort,
+top-300 (egs/voices_challenge/v1/steps_be/eval-be-snorm-v1.py:56-83 of the reference: three llr_1vs1
+calls and AdaptSNorm.predict).  One "step" = one pass of that path over synthetic 512-d x-vectors
+already resident in HBM: pre-processing chain + PLDA projection of enrolment, cohort and test
+vectors, the three score matrices, both top-k selections, both cohort-statistics gathers and the
+normalisation, the [n_enrol, n_test] result left in HBM.
 
-Prints ONE JSON line on rank 0.
+--gpus N > 1 without a torch.distributed environment starts N ranks itself (one process per GPU,
+RCCL); every rank scores the same enrolment set against its own shard of tests (per-GPU work is
+fixed: weak scaling) and the reported value is what all ranks produced divided by the slowest
+rank's time.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -24,16 +27,14 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+METRIC = "PLDA trial scores/sec (512-d, SPLDA+AS-norm) at 1/8 GPU; % fp32 MFMA peak"
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (256 CU x 256 flop/clk x 2.4 GHz)
-BF16_MFMA_PEAK_TFLOPS = 2516.6  # dense bf16 matrix peak (256 CU x 4096 flop/clk x 2.4 GHz)
+F16_MFMA_PEAK_TFLOPS = 2516.6  # dense fp16 / bf16 matrix peak (256 CU x 4096 flop/clk x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
-LDS_PEAK_GBS = 256 * 128 * 2.4  # GB/s: 128 bytes per clock and CU
+LDS_PEAK_GBS = 256 * 256 * 2.4  # GB/s: 256 CUs x 256 bytes per clock (ds_read_b64 / b128) x 2.4 GHz
 
 WORKLOADS = {
     # n_enrol, n_test per GPU, input dim, LDA dim, y_dim; asnorm: cohort size and nbest
-    "chain_splda_100k": dict(n_enrol=100_000, n_test=100_000, d=512, lda=200, K=150),
-    "chain_splda_20k": dict(n_enrol=20_000, n_test=20_000, d=512, lda=200, K=150),
-    "splda_vox1": dict(n_enrol=4874, n_test=4874, d=512, lda=None, K=150),
     "asnorm_10k_1m": dict(n_enrol=10_000, n_test=1_000_000, d=512, lda=200, K=150, n_coh=20_000, nbest=300),
     "asnorm_10k_128k": dict(n_enrol=10_000, n_test=131_072, d=512, lda=200, K=150, n_coh=20_000, nbest=300),
     # one GPU's share of the 1M x 1M matrix on 8 GPUs (125 000 tests per GPU: `--gpus 8` is the whole
@@ -42,26 +43,109 @@ WORKLOADS = {
                            sink=True, test_chunk=4096),
     "asnorm_100k_16k": dict(n_enrol=100_000, n_test=16_384, d=512, lda=200, K=150, n_coh=20_000, nbest=300,
                             sink=True, test_chunk=4096),
+    "asnorm_tiny": dict(n_enrol=300, n_test=2_000, d=512, lda=200, K=150, n_coh=1_000, nbest=100),
+    # raw scores only (no normalisation): chain + SPLDA, full score matrix
+    "chain_splda_100k": dict(n_enrol=100_000, n_test=100_000, d=512, lda=200, K=150),
+    "chain_splda_20k": dict(n_enrol=20_000, n_test=20_000, d=512, lda=200, K=150),
+    "splda_vox1": dict(n_enrol=4874, n_test=4874, d=512, lda=None, K=150),
 }
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="chain_splda_100k", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="asnorm_10k_1m", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-stages", action="store_true",
+                    help="skip the extra stage measurements (100k x 100k score matrix) of the default workload")
     ap.add_argument("--cpu-sample", type=int, default=20000,
-                    help="rows/cols of the square slice the CPU baseline is timed on")
+                    help="rows/cols of the square slice the raw-score CPU baseline is timed on")
     ap.add_argument("--split-format", default="pair", choices=["pair", "triple", "none"],
                     help="operands of the score kernel: scaled fp16 pairs, exact bf16 triples, or fp32")
-    ap.add_argument("--no-asnorm-stage", action="store_true",
-                    help="skip the extra AS-norm stage measurement of the default workload")
-    return ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="start the ranks, form the process group, exchange one number, print the rank "
+                         "count and stop (no GPU work): a check of the launch path")
+    return ap.parse_args(argv)
 
 
+# ---- launching N ranks -------------------------------------------------------------------------
+def rehearsing():
+    """HYPMI_BENCH_REHEARSE=1: every rank on GPU 0 with the gloo backend -- a rehearsal of the multi-rank
+    flow on a one-GPU (or, with --dry-run, no-GPU) machine; its throughput means nothing."""
+    return os.environ.get("HYPMI_BENCH_REHEARSE", "0") == "1"
+
+
+def launch_ranks(args):
+    """Parent of a `--gpus N` run that was not started by a launcher: starts N fresh rank processes
+    (python -m torch.distributed.run, one per GPU) before anything here has touched a GPU, and
+    returns their exit code.  Rank 0 of the children prints the JSON line."""
+    import socket
+    import subprocess
+
+    if not rehearsing():
+        import torch
+
+        have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+        if have < args.gpus:
+            print("bench.py: --gpus %d but only %d GPU(s) are visible" % (args.gpus, have), file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def init_ranks(args):
+    """(world, rank, dist) of this process; forms the process group when there is more than one rank and
+    fails loudly when the group is not the size --gpus asked for."""
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        if rehearsing():
+            import faulthandler
+
+            faulthandler.dump_traceback_later(int(os.environ.get("HYPMI_BENCH_WATCHDOG_S", "100")), exit=True)
+            dist.init_process_group("gloo")
+        else:
+            import torch
+
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        seen = dist.get_world_size()
+        if seen != args.gpus:
+            print("bench.py: --gpus %d but the process group has %d rank(s)" % (args.gpus, seen), file=sys.stderr)
+            dist.destroy_process_group()
+            sys.exit(3)
+    elif args.gpus != 1:
+        print("bench.py: --gpus %d but WORLD_SIZE is 1" % args.gpus, file=sys.stderr)
+        sys.exit(3)
+    return world, rank, local_rank, dist
+
+
+def dry_run(args, world, rank, dist):
+    import torch
+
+    t = torch.ones(1, dtype=torch.int64)
+    if world > 1:
+        if not rehearsing():
+            t = t.cuda()
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": int(t.item()), "requested": args.gpus,
+                          "backend": dist.get_backend() if world > 1 else None}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+# ---- workload ----------------------------------------------------------------------------------
 def build_workload(cfg):
     """Host-side synthetic model + chain (float64 parameters)."""
     import synth
@@ -84,26 +168,49 @@ def make_inputs(cfg, n, seed):
     return x.astype(np.float32)
 
 
-def cpu_baseline(cfg, chain, model, sample):
-    """The float64 numpy oracle (same operation sequence as the reference) timed on a bounded
-    square slice of the same workload."""
-    from oracle import plda_ref as O
+def device_xvectors(n, d, seed, num_centers=10_000):
+    """Raw x-vectors drawn on the device (0.5 x class centre + unit noise, class = row % num_centers):
+    the shape of synth.raw_xvectors without a host round trip."""
+    import torch
 
-    try:
-        from threadpoolctl import threadpool_info
+    g = torch.Generator(device="cuda").manual_seed(20)
+    C = torch.randn((num_centers, d), device="cuda", generator=g)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    cls = torch.arange(n, device="cuda") % num_centers
+    x = torch.empty((n, d), device="cuda")
+    for r0 in range(0, n, 1 << 18):  # in slices: no second full-size temporary
+        r1 = min(n, r0 + (1 << 18))
+        x[r0:r1] = torch.randn((r1 - r0, d), device="cuda", generator=g)
+        x[r0:r1] += 0.5 * C[cls[r0:r1]]
+    return x, cls.to(torch.int32)
 
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count()
-    cpu_model = "unknown"
+
+def host_cpu():
+    """(model name, threads numpy's BLAS uses) of the host the CPU baseline runs on."""
+    model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
             for line in f:
                 if line.startswith("model name"):
-                    cpu_model = line.split(":", 1)[1].strip()
+                    model = line.split(":", 1)[1].strip()
                     break
     except OSError:
         pass
+    try:
+        from threadpoolctl import threadpool_info
+
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:  # noqa: BLE001
+        cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count()))
+    return model, int(cores)
+
+
+def cpu_baseline(cfg, chain, model, sample):
+    """The float64 numpy oracle (same operation sequence as the reference) timed on a bounded
+    square slice of a raw-score workload."""
+    from oracle import plda_ref as O
+
+    cpu, cores = host_cpu()
     n = min(sample, cfg["n_enrol"], cfg["n_test"])
     x1 = make_inputs(cfg, n, 31).astype(np.float64)
     x2 = make_inputs(cfg, n, 32).astype(np.float64)
@@ -115,16 +222,17 @@ def cpu_baseline(cfg, chain, model, sample):
     s = O.llr_1vs1(model, y1, y2)
     dt = time.perf_counter() - t0
     del s
-    return {"value": n * n / dt, "unit": "scores/s", "cores": int(cores), "kind": "port", "cpu": cpu_model,
+    return {"value": n * n / dt, "unit": "scores/s", "cores": cores, "kind": "port", "cpu": cpu,
             "sample": "%d x %d trials (chain on 2 x %d vectors + SPLDA llr_1vs1), float64 numpy, %.2f s"
                       % (n, n, n, dt)}
 
 
 def cpu_baseline_asnorm(cfg, chain, model, n_enrol=1000, n_test=4000):
-    """The float64 oracle on the host for the AS-norm workloads: chain + SPLDA scores of a slice
-    against the full cohort, then the reference's adaptive S-norm loops."""
+    """The float64 oracle on the host for the AS-norm workloads: chain + SPLDA scores of a slice of
+    the trial matrix against the full cohort, then the reference's adaptive S-norm loops."""
     from oracle import plda_ref as O
 
+    cpu, cores = host_cpu()
     nc, nbest = cfg["n_coh"], cfg["nbest"]
     ne, nt = min(n_enrol, cfg["n_enrol"]), min(n_test, cfg["n_test"])
     xe, xt, xc = (make_inputs(cfg, n, seed).astype(np.float64) for n, seed in ((ne, 41), (nt, 43), (nc, 42)))
@@ -132,9 +240,9 @@ def cpu_baseline_asnorm(cfg, chain, model, n_enrol=1000, n_test=4000):
     ye, yt, yc = (O.chain_predict(x, chain) for x in (xe, xt, xc))
     O.adapt_s_norm(O.llr_1vs1(model, ye, yt), O.llr_1vs1(model, yc, yt), O.llr_1vs1(model, ye, yc), nbest, 0)
     dt = time.perf_counter() - t0
-    return {"value": ne * nt / dt, "unit": "scores/s", "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count())),
-            "kind": "port", "sample": "%d enrol x %d test against the %d cohort (chain + SPLDA + AdaptSNorm, "
-            "float64 numpy), %.2f s" % (ne, nt, nc, dt)}
+    return {"value": ne * nt / dt, "unit": "scores/s", "cores": cores, "kind": "port", "cpu": cpu,
+            "sample": "%d enrol x %d test against the whole %d-member cohort (chain + 3 x SPLDA llr_1vs1 + "
+                      "AdaptSNorm nbest %d, float64 numpy), %.2f s" % (ne, nt, nc, nbest, dt)}
 
 
 def profiled_traffic(workload):
@@ -149,28 +257,25 @@ def profiled_traffic(workload):
         return None
 
 
-def asnorm_stage(plda, preproc, cfg, n_test, steps, warmup, rank, world=1):
-    """Chain + SPLDA + adaptive S-norm (20k cohort, top-300) for n_test test vectors against 10k
-    enrolment models, everything device resident; returns normalised scores/s of one GPU."""
+# ---- AS-norm workloads -------------------------------------------------------------------------
+def asnorm_run(plda, preproc, cfg, steps, warmup, rank, world, dist):
+    """Times `steps` passes of chain + SPLDA + adaptive S-norm; returns (seconds per step of this rank
+    between barriers, stage dict, backend, buffers)."""
     import torch
 
     from hyperion_amd import engine
     from hyperion_amd.backend import PLDABackend
 
-    ne = cfg["n_enrol"] if "n_coh" in cfg else 10_000  # the default workload appends a 10k-enrol stage
-    nc, nbest = cfg.get("n_coh", 20_000), cfg.get("nbest", 300)
+    ne, nt = cfg["n_enrol"], cfg["n_test"]
+    nc, nbest = cfg["n_coh"], cfg["nbest"]
     sink = bool(cfg.get("sink"))
     be = PLDABackend(plda, preproc, nbest=nbest, test_chunk=cfg.get("test_chunk", 65536))
-    if sink:  # too large for host-side generation and for a materialised result
-        xe, ke = device_xvectors(ne, cfg["d"], 41)
-        xc, _ = device_xvectors(nc, cfg["d"], 42)
-        xt, kt = device_xvectors(n_test, cfg["d"], 43 + 1000 * rank)
-        out = None
-    else:
-        xe = engine.upload(make_inputs(cfg, ne, 41))
-        xc = engine.upload(make_inputs(cfg, nc, 42))
-        xt = engine.upload(make_inputs(cfg, n_test, 43 + 1000 * rank))
-        out = torch.empty((ne, engine.round_up(n_test, 32)), dtype=torch.float32, device="cuda")[:, :n_test]
+    xe, ke = device_xvectors(ne, cfg["d"], 41)
+    xc, _ = device_xvectors(nc, cfg["d"], 42)
+    xt, kt = device_xvectors(nt, cfg["d"], 43 + 1000 * rank)  # every rank owns a different test shard
+    out = None
+    if not sink:
+        out = torch.empty((ne, engine.round_up(nt, 32)), dtype=torch.float32, device="cuda")[:, :nt]
     hists = []
 
     def step():
@@ -188,51 +293,42 @@ def asnorm_stage(plda, preproc, cfg, n_test, steps, warmup, rank, world=1):
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    be.trace = []  # HIP events around the launches of the timed steps (on the stream they run on)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    st = {"workload": "chain+SPLDA+AdaptSNorm: %d enrol x %d test per GPU, cohort %d, nbest %d%s"
-                      % (ne, n_test, nc, nbest, ", streamed into tar/non histograms" if sink else ""),
-          "value": ne * n_test / dt, "unit": "normalised scores/s", "ms_per_step": dt * 1e3,
-          "gather_GBs": 2.0 * nbest * 4 * ne * n_test / dt / 1e9}
+    trace, be.trace = be.trace, None
+    per = {}
+    for name, e0, e1, shape in trace:
+        per.setdefault(name, []).append((e0.elapsed_time(e1), shape))
+    st = {"per_step_ms": {k: float(sum(ms for ms, _ in v)) / steps for k, v in per.items()}}
+    # the dominant kernel: the cohort-statistics gather (two launches per test chunk)
+    g = per.get("gather_z", []) + per.get("gather_t", [])
+    if g:
+        avg_ms = float(np.mean([ms for ms, _ in g]))
+        avg_bytes = float(np.mean([4.0 * r * q * k for _, (r, q, k) in g]))
+        st["gather"] = {"launches_per_step": len(g) // steps, "avg_launch_ms": avg_ms,
+                        "algorithmic_bytes_per_launch": avg_bytes}
     if sink:
         h = hists[0]
         m = h.moments()
         st["sink"] = {"trials": m["tar"]["count"] + m["non"]["count"], "tar": m["tar"], "non": m["non"],
                       "eer": h.eer(), "min_dcf_0.05": h.min_dcf(0.05)[0]}
-        second = h.exact_pass()
-        # outside the timed region: the second pass that makes the hull exact, when what it has to
-        # keep fits comfortably (it re-scores everything)
-        if second is not None and world == 1 and sum(second.expect) <= 2_000_000_000:
-            t0 = time.perf_counter()
-            be.score_snorm(xt, be.prepare_cohort(xe, xc), reduce=second.sink(ke, kt))
-            second.finish()
-            st["sink"].update({"exact_eer": h.eer(), "exact_min_dcf_0.05": h.min_dcf(0.05)[0],
-                               "second_pass_s": time.perf_counter() - t0,
-                               "second_pass_scores_kept": int(sum(second.expect))})
     else:
         st["checksum"] = float(out.sum(dtype=torch.float64).item())
-    return st, be, (xe, xc, xt, out)
-
-
-def device_xvectors(n, d, seed, num_centers=10_000):
-    """Raw x-vectors drawn on the device (0.5 x class centre + unit noise, class = row % num_centers):
-    the shape of synth.raw_xvectors without a host round trip, for the million-vector workloads."""
-    import torch
-
-    g = torch.Generator(device="cuda").manual_seed(20)
-    C = torch.randn((num_centers, d), device="cuda", generator=g)
-    g = torch.Generator(device="cuda").manual_seed(seed)
-    cls = torch.arange(n, device="cuda") % num_centers
-    x = torch.randn((n, d), device="cuda", generator=g)
-    x += 0.5 * C[cls]
-    return x, cls.to(torch.int32)
+    return dt, st, be, (xe, xc, xt, out)
 
 
 def asnorm_check(be, bufs, chain, model, cfg):
-    """Spot check of the AS-norm output against the oracle on a slab (all 20k cohort, 8 enrol rows,
+    """Spot check of the AS-norm output against the oracle on a slab (whole cohort, 8 enrol rows,
     64 tests): the slab's rows/columns are recomputed on the CPU from the same raw inputs."""
     from oracle import plda_ref as O
 
@@ -248,48 +344,132 @@ def asnorm_check(be, bufs, chain, model, cfg):
     return float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)))
 
 
-def main():
-    args = parse()
+def score_matrix_stage(plda, preproc, n=100_000, reps=3):
+    """The score-matrix stage on its own at the size of the fused-chain configuration (n x n trials,
+    chain + SPLDA): the fp32-MFMA kernel against the fp32 matrix peak, and the default fp16-pair
+    kernel against HBM (its products run on the 16-bit pipe, its stores bind it)."""
     import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # HYPMI_BENCH_REHEARSE=1: every rank on GPU 0 with the gloo backend -- a rehearsal of the multi-rank
-    # flow on a one-GPU machine (its throughput means nothing); the real launch is one rank per GPU over RCCL.
-    rehearse = os.environ.get("HYPMI_BENCH_REHEARSE", "0") == "1"
-    if world > 1 and rehearse:
-        import faulthandler
-
-        faulthandler.dump_traceback_later(int(os.environ.get("HYPMI_BENCH_WATCHDOG_S", "100")), exit=True)
-        torch.cuda.set_device(0)
-        dist.init_process_group("gloo")
-    elif world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-
-    from hyperion_amd import engine
+    from hyperion_amd import _lib, engine
     from hyperion_amd.engine import SIDE_ENROL, SIDE_TEST
-    from hyperion_amd.pdfs.plda import SPLDA
-    from hyperion_amd.transforms import LDA, CentWhiten, LNorm, TransformList
 
-    cfg = WORKLOADS[args.workload]
-    chain, model = build_workload(cfg)
-    plda = SPLDA(mu=model["mu"], V=model["V"], W=model["W"])
-    preproc = None
-    if chain is not None:
-        preproc = TransformList([CentWhiten(mu=chain[0][1], T=chain[0][2], name="cw"), LNorm(name="ln"),
-                                 LDA(mu=chain[2][1], T=chain[2][2], name="lda")])
     plan = plda.score_plan(preproc)
+    x1, _ = device_xvectors(n, 512, 21)
+    x2, _ = device_xvectors(n, 512, 22)
+    S = torch.empty((n, engine.round_up(n, 32)), dtype=torch.float32, device="cuda")[:, :n]
+    K = plda.y_dim
+    res = {"trials": "%d x %d" % (n, n)}
+    for name, fmt in (("fp32_mfma", None), ("fp16_pair", "pair")):
+        ms_score, ms_step = [], []
+        for it in range(reps + 1):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record()
+            G1, G2 = plan.prologue(x1, SIDE_ENROL), plan.prologue(x2, SIDE_TEST)
+            if fmt:
+                G1, G2 = engine.split_rows(G1, fmt), engine.split_rows(G2, fmt)
+            e[1].record()
+            engine.score(G1, G2, out=S, split=False)
+            e[2].record()
+            torch.cuda.synchronize()
+            if it:  # the first pass warms up
+                ms_score.append(e[1].elapsed_time(e[2]))
+                ms_step.append(e[0].elapsed_time(e[2]))
+        ms, step = float(np.mean(ms_score)), float(np.mean(ms_step))
+        tf = 2.0 * K * n * n / (ms * 1e-3) / 1e12
+        row_bytes = 4.0 * plan.kp if not fmt else float(getattr(_lib.load(), engine.SPLIT_FORMATS[fmt][0])(plan.kp))
+        gbs = (4.0 * n * n + 2 * n * row_bytes) / (ms * 1e-3) / 1e9
+        res[name] = {"score_kernel_ms": ms, "step_ms": step, "scores_per_s": n * float(n) / (step * 1e-3),
+                     "algorithmic_fp32_TFLOPs": tf, "pct_fp32_mfma_peak": 100.0 * tf / FP32_MFMA_PEAK_TFLOPS,
+                     "hbm_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
+    res["fp16_pair"]["note"] = ("products on the fp16 matrix cores (3 partial products per fp32 product), so the "
+                                "fp32 matrix peak is not this kernel's roof: HBM stores are")
+    return res
 
-    if "n_coh" in cfg:
-        return main_asnorm(args, cfg, chain, model, plda, preproc, plan, world, rank, dist)
 
+def main_asnorm(args, cfg, chain, model, plda, preproc, world, rank, dist):
+    """AS-norm workloads: value = normalised scores/s over all ranks (test rows sharded)."""
+    import torch
+
+    dt, st, be, bufs = asnorm_run(plda, preproc, cfg, args.steps, args.warmup, rank, world, dist)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ne, nt, nc, nbest = cfg["n_enrol"], cfg["n_test"], cfg["n_coh"], cfg["nbest"]
+    sink = bool(cfg.get("sink"))
+    out = {
+        "metric": METRIC, "value": ne * float(nt) * world / dt, "unit": "scores/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None,
+        # the arithmetic types that execute: score matrices = scaled fp16 pairs on the matrix cores with
+        # fp32 accumulation (fp32-equivalent accuracy); selection, cohort statistics, normalisation = fp32
+        "dtype": "f32 (score products: fp16-pair split, f32 accumulate)", "data": "synthetic",
+        "config": {"workload": "%s: CentWhiten(512x512)+LNorm+LDA(200)+SPLDA(y_dim 150) scores with adaptive "
+                               "S-norm, %d enrol x %d test per GPU, cohort %d, nbest %d%s"
+                               % (args.workload, ne, nt, nc, nbest,
+                                  ", streamed into tar/non histograms" if sink else ", result kept in HBM"),
+                   "n_enrol": ne, "n_test_per_gpu": nt, "n_cohort": nc, "nbest": nbest, "x_dim": cfg["d"],
+                   "per_gpu": "one whole MI355X per rank (SPX mode), not an XCD partition",
+                   "parallelism": "test rows sharded over %d GPU(s), enrol and cohort replicated, one "
+                                  "all-gather of top-k lists" % world},
+        "roofline": None,
+        "stages_ms_per_step": st["per_step_ms"],
+    }
+    if "gather" in st:
+        g = st["gather"]
+        ach = g["algorithmic_bytes_per_launch"] / (g["avg_launch_ms"] * 1e-3) / 1e9
+        out["roofline"] = {
+            "kernel": "gather_pivot_kernel<2>", "bound": "lds", "achieved": ach, "peak": LDS_PEAK_GBS,
+            "unit": "GB/s", "frac": ach / LDS_PEAK_GBS, "traffic": profiled_traffic(args.workload),
+            "avg_launch_ms": g["avg_launch_ms"], "launches_per_step": g["launches_per_step"],
+            "algorithmic_bytes_per_launch": g["algorithmic_bytes_per_launch"],
+            "note": "cohort-statistics gather, %.0f %% of the step: one gathered fp32 (4 B) per (row, list, member) "
+                    "from LDS-resident rows; peak = conflict-free LDS read rate (256 B/clk/CU).  The loop is bound "
+                    "by instruction issue, not LDS bytes: per 8 gathered bytes a SIMD issues one address op, one "
+                    "ds_read_b64 and four plain f32 ops, measured floor 6.6 clk per wave-entry per CU = 0.30 of this "
+                    "peak (tools/probes/gather_rate.hip)"
+                    % (100.0 * g["avg_launch_ms"] * g["launches_per_step"] / (dt * 1e3))}
+    if "sink" in st:
+        out["sink"] = st["sink"]
+    else:
+        out["checksum"] = st["checksum"]
+    if rank == 0 and not args.no_check and chain is not None:
+        out["parity"] = {"max_err_over_max_abs_1": asnorm_check(be, bufs, chain, model, cfg),
+                         "slab": "8 enrol x 64 test, whole cohort, float64 oracle"}
+    try:
+        import ctypes
+
+        from hyperion_amd import _lib
+
+        redo = ctypes.c_ulonglong(0)
+        _lib.check(_lib.load().hypmi_gather_redo_count(ctypes.byref(redo), 0))
+        out["gather_pairs_redone_with_list_pivot"] = int(redo.value)
+    except Exception:  # noqa: BLE001
+        pass
+    del be, bufs
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_stages and args.workload == "asnorm_10k_1m":
+        try:  # extra measurements: a failure here must not cost the line its headline
+            out["score_matrix_stage"] = score_matrix_stage(plda, preproc)
+        except Exception as e:  # noqa: BLE001
+            out["score_matrix_stage"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and chain is not None:
+        try:
+            out["cpu_baseline"] = cpu_baseline_asnorm(cfg, chain, model)
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if rank == 0:
+        print(json.dumps(out))
+
+
+# ---- raw-score workloads -----------------------------------------------------------------------
+def main_scores(args, cfg, chain, model, plda, preproc, world, rank, dist):
+    import torch
+
+    from hyperion_amd import _lib, engine
+    from hyperion_amd.engine import SIDE_ENROL, SIDE_TEST
+
+    plan = plda.score_plan(preproc)
     n1, n2 = cfg["n_enrol"], cfg["n_test"]
     x1_h = make_inputs(cfg, n1, 21)
     x2_h = make_inputs(cfg, n2, 22 + 1000 * rank)  # every rank owns a different test shard
@@ -300,31 +480,25 @@ def main():
     torch.cuda.synchronize()
 
     ev_pairs, ev_pro = [], []
-
     fmt = args.split_format
     use_split = fmt != "none" and engine.split_rows(plan.prologue(x1[:1], SIDE_ENROL), fmt) is not None
     products = {"pair": 3, "triple": 6}.get(fmt, 1)
 
     def step(record):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
         if record:
-            p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            p0.record()
+            ev[0].record()
         G1 = plan.prologue(x1, SIDE_ENROL)
         G2 = plan.prologue(x2, SIDE_TEST)
         if use_split:  # 16-bit matrix cores at fp32 accuracy
             G1, G2 = engine.split_rows(G1, fmt), engine.split_rows(G2, fmt)
         if record:
-            p1.record()
-            ev_pro.append((p0, p1))
+            ev[1].record()
+        engine.score(G1, G2, out=S, split=False)
         if record:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            engine.score(G1, G2, out=S, split=False)
-            e1.record()
-            ev_pairs.append((e0, e1))
-        else:
-            engine.score(G1, G2, out=S, split=False)
+            ev[2].record()
+            ev_pro.append((ev[0], ev[1]))
+            ev_pairs.append((ev[1], ev[2]))
 
     for _ in range(args.warmup):
         step(False)
@@ -349,26 +523,18 @@ def main():
     pro_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pro]))
     # algorithmic prologue traffic: the 512-d input read once, K + 1 floats (g, q) written per vector
     pro_bytes = float(n1 + n2) * (4.0 * cfg["d"] + 4.0 * (cfg["K"] + 1))
-    scores_per_step = float(n1) * float(n2) * world
-    value = scores_per_step * args.steps / dt
     K = cfg["K"]
     achieved_tflops = 2.0 * K * n1 * n2 / (score_ms * 1e-3) / 1e12
     # the split kernels execute 3 (fp16 pairs) or 6 (bf16 triples) partial products per fp32 product
     # over the K + 2 packed columns
     executed_tflops = products * 2.0 * (K + 2) * n1 * n2 / (score_ms * 1e-3) / 1e12
-
     out = {
-        "metric": "PLDA trial scores/sec (512-d, SPLDA)",
-        "value": value,
-        "unit": "scores/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
+        "metric": "PLDA trial scores/sec (512-d, SPLDA, no score normalisation)",
+        "value": float(n1) * float(n2) * world * args.steps / dt, "unit": "scores/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": {"pair": "fp16-pair split products, f32 accumulate", "triple": "bf16-triple split products, "
+                  "f32 accumulate", "none": "f32"}[fmt if use_split else "none"],
         "data": "synthetic",
         "config": {
             "workload": "%s: CentWhiten(512x512)+LNorm+LDA(%s)+SPLDA(y_dim %d) prologue on %d enrol + %d "
@@ -381,49 +547,37 @@ def main():
     }
     # Two roofs for the score launch.  With 16-bit operands the matrix pipes need less time than the
     # 4 bytes per score need HBM, so HBM is the binding roof there; the fp32 kernel is matrix-bound.
-    from hyperion_amd import _lib
-
     row_bytes = 4.0 * plan.kp
     if use_split:
         row_bytes = float(getattr(_lib.load(), engine.SPLIT_FORMATS[fmt][0])(plan.kp))
-    # algorithmic bytes: the score matrix written once plus both operands read once
-    hbm_bytes = 4.0 * n1 * n2 + (n1 + n2) * row_bytes
+    hbm_bytes = 4.0 * n1 * n2 + (n1 + n2) * row_bytes  # the matrix written once, both operands read once
     hbm_view = {"bound": "hbm", "achieved": hbm_bytes / (score_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": hbm_bytes / (score_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_launch": hbm_bytes,
-                "hbm_store_GBs": 4.0 * n1 * n2 / (score_ms * 1e-3) / 1e9}
+                "algorithmic_bytes_per_launch": hbm_bytes}
     mfma_view = {"bound": "mfma", "achieved": achieved_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": achieved_tflops / FP32_MFMA_PEAK_TFLOPS,
-                 "algorithmic_flops_per_launch": 2.0 * K * n1 * n2,
-                 "note": ("algorithmic fp32 flops (2 K per score) against the fp32 matrix peak; above 1 because "
-                          "the products run on the 16-bit matrix cores (%s)" % (
-                              "scaled fp16 pairs, 3 partial products" if fmt == "pair" else
-                              "exact bf16 triples, 6 partial products")) if use_split else "fp32 matrix cores"}
+                 "algorithmic_flops_per_launch": 2.0 * K * n1 * n2}
     head = dict(hbm_view if use_split else mfma_view)
     head["kernel"] = (("score_split_kernel<%d,%d>" % (2 if fmt == "pair" else 3, (plan.kp + 31) // 32)) if use_split
                       else "score_rs_kernel<%d,2>" % plan.kp)
     head["traffic"] = profiled_traffic(args.workload)
     head["avg_launch_ms"] = score_ms
     head["hbm" if not use_split else "mfma_fp32_equivalent"] = hbm_view if not use_split else mfma_view
+    if use_split:
+        head["executed"] = {"pipe": "%s MFMA (%d partial products per fp32 product, K + 2 packed columns)"
+                                    % ("fp16" if fmt == "pair" else "bf16", products),
+                            "achieved": executed_tflops, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": executed_tflops / F16_MFMA_PEAK_TFLOPS}
     out["roofline"] = head
     out["prologue_stage"] = {
         "what": "pre-processing chain + PLDA projection + packing (+ 16-bit split) of %d + %d vectors" % (n1, n2),
         "ms": pro_ms, "bound": "hbm", "achieved": pro_bytes / (pro_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": pro_bytes / (pro_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "algorithmic_bytes": pro_bytes,
-        "note": "matrix-core bound in practice: see mfma"}
+        "unit": "GB/s", "frac": pro_bytes / (pro_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": pro_bytes}
     if chain is not None:  # u = x A1 (d x d, for the length norm) and x (A1 A2) (d x 2K) on the fp32 matrix cores
         pro_flops = 2.0 * cfg["d"] * (cfg["d"] + 2 * K) * (n1 + n2)
         out["prologue_stage"]["mfma"] = {"achieved": pro_flops / (pro_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
-                                         "unit": "TFLOP/s", "frac": pro_flops / (pro_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                                         "algorithmic_flops": pro_flops}
-    if use_split:
-        out["roofline"]["executed"] = {
-            "pipe": "%s MFMA (%d partial products per fp32 product, K + 2 packed columns)"
-                    % ("fp16" if fmt == "pair" else "bf16", products),
-            "achieved": executed_tflops, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": executed_tflops / BF16_MFMA_PEAK_TFLOPS}
-
+                                         "unit": "TFLOP/s",
+                                         "frac": pro_flops / (pro_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
     if rank == 0 and not args.no_check:
         # parity spot check outside the timed region: a slab of the device matrix vs the oracle
         from oracle import plda_ref as O
@@ -438,16 +592,6 @@ def main():
         err = np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)
         out["parity"] = {"max_err_over_max_abs_1": float(err.max()), "slab": [r, c],
                          "checksum": float(S.sum(dtype=torch.float64).item())}
-    if rank == 0 and world == 1 and not args.no_asnorm_stage and chain is not None:
-        del S
-        torch.cuda.empty_cache()
-        try:  # an extra measurement: a failure here must not cost the line its headline
-            st, be, bufs = asnorm_stage(plda, preproc, cfg, 131_072, 2, 1, rank)
-            if not args.no_check:
-                st["parity_max_err_over_max_abs_1"] = asnorm_check(be, bufs, chain, model, cfg)
-            out["asnorm_stage"] = st
-        except Exception as e:  # noqa: BLE001
-            out["asnorm_stage"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(cfg, chain, model, args.cpu_sample)
@@ -455,49 +599,31 @@ def main():
             out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
 
 
-def main_asnorm(args, cfg, chain, model, plda, preproc, plan, world, rank, dist):
-    """AS-norm workloads: value = normalised scores/s over all ranks (test rows sharded)."""
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))  # nothing in this process has touched a GPU
+    world, rank, local_rank, dist = init_ranks(args)
+    if args.dry_run:
+        return dry_run(args, world, rank, dist)
     import torch
 
-    if world > 1:
-        dist.barrier()
-    st, be, bufs = asnorm_stage(plda, preproc, cfg, cfg["n_test"], args.steps, args.warmup, rank, world)
-    dt = st["ms_per_step"] * 1e-3
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ne, nt = cfg["n_enrol"], cfg["n_test"]
-    out = {
-        "metric": "PLDA trial scores/sec (512-d, SPLDA+AS-norm)", "value": ne * nt * world / dt,
-        "unit": "scores/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": args.workload + ": " + st["workload"], "parallelism":
-                   "test rows sharded over %d GPU(s), enrol and cohort replicated" % world},
-        # the dominant kernel gathers from LDS, not from HBM: 2 x nbest fp32 values per normalised score
-        # against the LDS bandwidth of the chip (256 CUs x 128 B/clk x 2.4 GHz)
-        "roofline": {"kernel": "gather_stats_kernel<2,false>", "bound": "lds",
-                     "note": "random LDS gathers; achieved = gathered bytes (2 x nbest x 4 B per normalised "
-                             "score) / step time, the step including scoring, top-k and the sink",
-                     "achieved": st["gather_GBs"], "peak": LDS_PEAK_GBS, "unit": "GB/s",
-                     "frac": st["gather_GBs"] / LDS_PEAK_GBS, "traffic": None},
-    }
-    if "sink" in st:
-        out["sink"] = st["sink"]
-    if rank == 0 and not args.no_check and chain is not None:
-        out["parity"] = {"max_err_over_max_abs_1": asnorm_check(be, bufs, chain, model, cfg)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and chain is not None:
-        try:
-            out["cpu_baseline"] = cpu_baseline_asnorm(cfg, chain, model)
-        except Exception as e:  # noqa: BLE001
-            out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    if rank == 0:
-        print(json.dumps(out))
+    torch.cuda.set_device(0 if rehearsing() else local_rank)
+
+    from hyperion_amd.pdfs.plda import SPLDA
+    from hyperion_amd.transforms import LDA, CentWhiten, LNorm, TransformList
+
+    cfg = WORKLOADS[args.workload]
+    chain, model = build_workload(cfg)
+    plda = SPLDA(mu=model["mu"], V=model["V"], W=model["W"])
+    preproc = None
+    if chain is not None:
+        preproc = TransformList([CentWhiten(mu=chain[0][1], T=chain[0][2], name="cw"), LNorm(name="ln"),
+                                 LDA(mu=chain[2][1], T=chain[2][2], name="lda")])
+    run = main_asnorm if "n_coh" in cfg else main_scores
+    run(args, cfg, chain, model, plda, preproc, world, rank, dist)
     if world > 1:
         dist.destroy_process_group()
 

@@ -75,6 +75,20 @@ class PLDABackend:
         # scores (costs one fp64 prologue per vector; without it ~0.05 % of test columns pick one
         # different cohort member than float64 arithmetic would)
         self.exact_topk = bool(exact_topk)
+        # set to a list to record (stage, start event, end event, shape) of every launch group on the
+        # stream it runs on (bench.py: live kernel durations inside the timed step)
+        self.trace = None
+
+    def _timed(self, name, fn, shape=None):
+        if self.trace is None:
+            return fn()
+        torch = engine.require_gpu()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self.trace.append((name, e0, e1, shape))
+        return r
 
     # ---- embeddings ---------------------------------------------------------------------------
     def embed(self, x, side):
@@ -91,10 +105,10 @@ class PLDABackend:
         panel A_ec [n_enrol, n_cohort] and the per-enrolment top-k cohort lists.  With world > 1 each
         rank selects the lists of its own slice of enrolment rows and one all-gather makes them
         global (the only inter-GPU exchange of the whole pipeline)."""
-        Ge = self.embed(x_enrol, SIDE_ENROL)
+        Ge = self._timed("prologue", lambda: self.embed(x_enrol, SIDE_ENROL))
         xc = engine.upload(x_cohort)
-        Gc_test = self.plan.prologue(xc, SIDE_TEST)
-        A_ec = engine.score(Ge, Gc_test)
+        Gc_test = self._timed("prologue", lambda: self.plan.prologue(xc, SIDE_TEST))
+        A_ec = self._timed("score_enrol_cohort", lambda: engine.score(Ge, Gc_test))
         ne, nc = A_ec.shape
         assert self.nbest_discard < nc
         k = min(self.nbest, nc - self.nbest_discard)
@@ -107,7 +121,8 @@ class PLDABackend:
             xe64 = engine.upload64(x_enrol[lo:hi])
             Ge64, be = self.plan.prologue_f64(xe64, SIDE_ENROL)
             exact = dict(coh64, G_rows=Ge64, bnd_rows=be)
-        local = topk_rows(A_ec[lo:hi], k, self.nbest_discard, exact)[:, :hi - lo]  # [k/8, rows, 8]
+        local = self._timed("topk_enrol", lambda: topk_rows(A_ec[lo:hi], k, self.nbest_discard, exact))
+        local = local[:, :hi - lo]  # [k/8, rows, 8]
         e_idx = all_gather_lists(local.reshape(local.shape[0], -1), counts, group)
         e_idx = e_idx.reshape(e_idx.shape[0], -1, 8).contiguous()
         return {"Ge": Ge, "Gc_test": Gc_test, "A_ec": A_ec, "e_idx": e_idx, "k": k, "coh64": coh64}
@@ -131,25 +146,30 @@ class PLDABackend:
         for c0 in range(0, nt, self.test_chunk):
             c1 = min(nt, c0 + self.test_chunk)
             xc = xt[c0:c1]
-            Gt_rows = self.plan.prologue(xc, SIDE_ENROL)  # tests as rows of the cohort panel
-            Gt_cols = self.plan.prologue(xc, SIDE_TEST)   # tests as columns of the trial matrix
-            A_tc = engine.score(Gt_rows, cohort["Gc_test"])            # [chunk, cohort]
+            T = self._timed
+            Gt_rows = T("prologue", lambda: self.plan.prologue(xc, SIDE_ENROL))  # tests as rows of the cohort panel
+            Gt_cols = T("prologue", lambda: self.plan.prologue(xc, SIDE_TEST))   # tests as columns of the trial matrix
+            A_tc = T("score_test_cohort", lambda: engine.score(Gt_rows, cohort["Gc_test"]))  # [chunk, cohort]
             exact = None
             if cohort.get("coh64") is not None:
-                Gt64, bt = self.plan.prologue_f64(engine.upload64(x_test[c0:c1]), SIDE_ENROL)
-                exact = dict(cohort["coh64"], G_rows=Gt64, bnd_rows=bt)
-            t_idx = topk_rows(A_tc, k, self.nbest_discard, exact)      # [k, chunk]
-            mz, iz, ldz = gather_stats(A_ec, None, t_idx, c1 - c0, 1e-5, k)  # [enrol, chunk]
-            mt, it, ldt = gather_stats(A_tc, None, e_idx, ne, 1e-5, k)       # [chunk, enrol]
-            S = engine.score(Ge, Gt_cols)                              # [enrol, chunk]
+                def f64_rows():
+                    Gt64, bt = self.plan.prologue_f64(engine.upload64(x_test[c0:c1]), SIDE_ENROL)
+                    return dict(cohort["coh64"], G_rows=Gt64, bnd_rows=bt)
+                exact = T("prologue_f64", f64_rows)
+            t_idx = T("topk_test", lambda: topk_rows(A_tc, k, self.nbest_discard, exact))  # [k, chunk]
+            mz, iz, ldz = T("gather_z", lambda: gather_stats(A_ec, None, t_idx, c1 - c0, 1e-5, k),
+                            (ne, c1 - c0, k))                                             # [enrol, chunk]
+            mt, it, ldt = T("gather_t", lambda: gather_stats(A_tc, None, e_idx, ne, 1e-5, k),
+                            (c1 - c0, ne, k))                                             # [chunk, enrol]
+            S = T("score_trials", lambda: engine.score(Ge, Gt_cols))                      # [enrol, chunk]
             if reduce is None:
                 dst = out[:, c0:c1]
             else:
                 dst = torch.empty((ne, engine.round_up(c1 - c0, 32)), dtype=torch.float32,
                                   device=xt.device)[:, :c1 - c0]
-            _lib.check(lib.hypmi_asnorm_apply(engine._ptr(S), S.stride(0), ne, c1 - c0, engine._ptr(mz),
-                                              engine._ptr(iz), ldz, engine._ptr(mt), engine._ptr(it), ldt,
-                                              engine._ptr(dst), dst.stride(0), engine.stream_ptr()))
+            T("apply", lambda: _lib.check(lib.hypmi_asnorm_apply(
+                engine._ptr(S), S.stride(0), ne, c1 - c0, engine._ptr(mz), engine._ptr(iz), ldz, engine._ptr(mt),
+                engine._ptr(it), ldt, engine._ptr(dst), dst.stride(0), engine.stream_ptr())))
             if reduce is not None:
                 reduce(c0, dst)
         return out
