@@ -23,6 +23,19 @@ __device__ __forceinline__ float4 ld4_guard(const float* p, bool ok) {
     return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// The first `valid` (1..4) components of a 16-byte load, the rest zero: the pad columns behind a row
+// of K % 4 != 0 values belong to the caller's buffer and may hold anything (a NaN there would
+// otherwise reach the product although its weight is zero).
+__device__ __forceinline__ float4 ld4_head(const float* p, bool ok, int valid) {
+    float4 v = ld4_guard(p, ok);
+    if (valid < 4) {
+        v.w = 0.f;
+        if (valid < 3) v.z = 0.f;
+        if (valid < 2) v.y = 0.f;
+    }
+    return v;
+}
+
 __device__ __forceinline__ float f4_get(const float4& v, int e) {
     return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
 }
@@ -46,15 +59,16 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ A, int64_t ld
     float4 ra[BM / 32], rb[BN / 32];
     auto fetch = [&](int k0) {
         const bool kok = (k0 + lk) < K;
+        const int valid = K - (k0 + lk);  // >= 4 except in the last float4 of a row with K % 4 != 0
 #pragma unroll
         for (int i = 0; i < BM / 32; ++i) {
             const int64_t gm = m0 + lrow + 32 * i;
-            ra[i] = ld4_guard(A + gm * lda + k0 + lk, kok && gm < M);
+            ra[i] = ld4_head(A + gm * lda + k0 + lk, kok && gm < M, valid);
         }
 #pragma unroll
         for (int i = 0; i < BN / 32; ++i) {
             const int64_t gn = n0 + lrow + 32 * i;
-            rb[i] = ld4_guard(B + gn * ldb + k0 + lk, kok && gn < N);
+            rb[i] = ld4_head(B + gn * ldb + k0 + lk, kok && gn < N, valid);
         }
     };
 
