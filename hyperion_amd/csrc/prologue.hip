@@ -10,6 +10,8 @@
 
 #include <vector>
 
+#include <mutex>
+
 #include "common.h"
 #include "gemm_tile.h"
 
@@ -554,9 +556,68 @@ extern "C" int hypmi_lnorm_rows(float* y, int64_t n, int64_t ldy, int d, void* s
     return run_lnorm(y, n, ldy, d, static_cast<hipStream_t>(stream));
 }
 
+namespace {
+int prologue_impl(const hypmi_plan* p, const float* x, int64_t n, int64_t ldx, int side, float* G, void* ws,
+                  int64_t ws_bytes, hipStream_t stream);
+
+// Scratch of the entry point that allocates nothing: one array per GPU the library runs on, held
+// until the process ends.  The array's name is a host-side stand-in; its device address comes from
+// hipGetSymbolAddress, once per device, and that address is what kernels and copies are given.
+constexpr int64_t STATIC_SCRATCH_BYTES = 16ll << 20;
+constexpr int MAX_DEVICES = 64;
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+namespace {
+std::mutex scratch_mutex;
+void* scratch_ptr[MAX_DEVICES];
+
+int static_scratch(void** out) {
+    int dev = -1;
+    HYPMI_HIP(hipGetDevice(&dev));
+    HYPMI_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(scratch_mutex);
+    if (!scratch_ptr[dev]) {
+        void* ptr = nullptr;
+        HYPMI_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));  // this device's copy of the array
+        HYPMI_REQUIRE(ptr != nullptr, "no device address for the static scratch array");
+        scratch_ptr[dev] = ptr;
+    }
+    *out = scratch_ptr[dev];
+    return HYPMI_OK;
+}
+}  // namespace
+
+extern "C" int64_t hypmi_prologue_noalloc_max_rows(const hypmi_plan* p) {
+    if (!p) return 0;
+    const int64_t per_row = hypmi_prologue_workspace_bytes(p, 1);
+    const int64_t rows = per_row > 0 ? STATIC_SCRATCH_BYTES / per_row : 0;
+    return rows < CHUNK_ROWS ? rows : CHUNK_ROWS;
+}
+
+extern "C" int hypmi_prologue_noalloc(const hypmi_plan* p, const float* x, int64_t n, int64_t ldx, int side,
+                                      float* G, void* stream_) {
+    HYPMI_REQUIRE(p && p->K > 0, "prologue_noalloc: plan has no PLDA projection");
+    const int64_t max_rows = hypmi_prologue_noalloc_max_rows(p);
+    HYPMI_REQUIRE(n <= max_rows,
+                  "prologue_noalloc: %lld rows exceed the %lld this plan fits into the %lld-byte static scratch; "
+                  "use hypmi_prologue with a workspace",
+                  (long long)n, (long long)max_rows, (long long)STATIC_SCRATCH_BYTES);
+    void* ws = nullptr;
+    int rc = static_scratch(&ws);
+    if (rc != HYPMI_OK) return rc;
+    // Every intermediate row is written by its producing kernel before anything reads it and nothing
+    // is accumulated in place, so what the previous call left behind needs no clearing.
+    return prologue_impl(p, x, n, ldx, side, G, ws, STATIC_SCRATCH_BYTES, static_cast<hipStream_t>(stream_));
+}
+
 extern "C" int hypmi_prologue(const hypmi_plan* p, const float* x, int64_t n, int64_t ldx, int side,
                               float* G, void* ws, int64_t ws_bytes, void* stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    return prologue_impl(p, x, n, ldx, side, G, ws, ws_bytes, static_cast<hipStream_t>(stream_));
+}
+
+namespace {
+int prologue_impl(const hypmi_plan* p, const float* x, int64_t n, int64_t ldx, int side, float* G, void* ws,
+                  int64_t ws_bytes, hipStream_t stream) {
     HYPMI_REQUIRE(p && p->K > 0, "prologue: plan has no PLDA projection");
     HYPMI_REQUIRE(x && G, "prologue: null pointer");
     HYPMI_REQUIRE(n >= 0 && ldx >= round_up(p->d_in, 4) && ldx % 4 == 0 && aligned16(x),
@@ -594,6 +655,7 @@ extern "C" int hypmi_prologue(const hypmi_plan* p, const float* x, int64_t n, in
     }
     return HYPMI_OK;
 }
+}  // namespace
 
 extern "C" int hypmi_transform(const hypmi_plan* p, const float* x, int64_t n, int64_t ldx, float* y,
                                int64_t ldy, void* ws, int64_t ws_bytes, void* stream_) {

@@ -109,6 +109,18 @@ int64_t hypmi_prologue_workspace_bytes(const hypmi_plan* plan, int64_t n);
 int hypmi_prologue(const hypmi_plan* plan, const float* x, int64_t n, int64_t ldx, int side,
                    float* G, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* hypmi_prologue for callers that cannot allocate device memory or pass a workspace (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc): the intermediate rows live
+ * in a 16 MiB array inside the library's device image, one per GPU, held until the process ends.
+ * No counterpart in the reference.  Same arguments, result and stream ordering as hypmi_prologue;
+ * n may not exceed hypmi_prologue_noalloc_max_rows(plan) (3167 rows for a 512 -> 512 -> 200 chain
+ * with K = 150), larger n is refused with an error.  It calls no hipMalloc / hipFree.  All calls on
+ * one GPU share that GPU's array: calls that may overlap there (different streams or threads)
+ * race; keep them on one stream or order them yourself. */
+int64_t hypmi_prologue_noalloc_max_rows(const hypmi_plan* plan);
+int hypmi_prologue_noalloc(const hypmi_plan* plan, const float* x, int64_t n, int64_t ldx, int side,
+                           float* G, void* stream);
+
 /* Only the segments (TransformList.predict, transform_list.py:41-44): y is [n x d_out]. */
 int hypmi_transform(const hypmi_plan* plan, const float* x, int64_t n, int64_t ldx, float* y,
                     int64_t ldy, void* workspace, int64_t workspace_bytes, void* stream);
