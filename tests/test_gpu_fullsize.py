@@ -95,7 +95,8 @@ def test_chain_splda_100k_by_100k():
         _assert_close(_host64(S[rs, cs]), O.llr_1vs1(model, y1, y2))
 
 
-@pytest.mark.parametrize("kind,method", [("frplda", "vavg-lnorm"), ("plda", "savg"), ("frplda", "vavg")])
+@pytest.mark.parametrize("kind,method", [("frplda", "vavg-lnorm"), ("plda", "savg"), ("frplda", "vavg"),
+                                         ("frplda", "book"), ("plda", "book")])
 def test_nvsm_50k_enrol_of_3_by_200k(kind, method):
     """FRPLDA / PLDA multi-session enrolment: 50 000 models of 3 segments against 200 000
     single-segment tests (llr_Nvs1 = llr_NvsM with one segment per test)."""
@@ -117,6 +118,24 @@ def test_nvsm_50k_enrol_of_3_by_200k(kind, method):
         seg = slice(m0 * segs, (m0 + 40) * segs)
         ref = O.llr_Nvs1(model, _host64(x1[seg]), _host64(x2[c0:c0 + 64]), ids1=ids1[seg] - m0, method=method)
         _assert_close(_host64(S[m0:m0 + 40, c0:c0 + 64]), ref)
+    if method == "book":
+        # By-the-book scoring packs its rows per count group in the model's eigenbasis; the whole-matrix
+        # property used here is that the matrix is the sum of an enrol term, a test term and one
+        # bilinear form: the second difference over any 2 x 2 minor is the bilinear part alone, which
+        # the oracle gives from the same four vectors (segment sets).
+        import torch
+
+        rows = torch.tensor([3, 17_777, n_models - 2], device="cuda")
+        cols = torch.tensor([9, 150_001, n2 - 3], device="cuda")
+        sub = _host64(S[rows][:, cols])
+        seg_rows = np.concatenate([np.arange(int(r) * segs, (int(r) + 1) * segs) for r in rows.cpu()])
+        ref = O.llr_Nvs1(model, _host64(x1[torch.from_numpy(seg_rows).cuda()]), _host64(x2[cols]),
+                         ids1=np.repeat(np.arange(3), segs), method="book")
+        _assert_close(sub, ref)
+        d2 = sub[0, 0] - sub[0, 1] - sub[1, 0] + sub[1, 1]
+        r2 = ref[0, 0] - ref[0, 1] - ref[1, 0] + ref[1, 1]
+        assert abs(d2 - r2) <= 1e-3 * max(1.0, abs(r2))
+        return
     # whole-matrix property: the score is bilinear in the packed rows that were multiplied
     if method == "savg":
         from hyperion_amd.pdfs.plda.plda_base import pool_rows
@@ -136,22 +155,32 @@ def pool_rows_mean(x, ids):
     return pool_rows(x, ids, mean=True)[0]
 
 
-def test_adapt_s_norm_10k_enrol_by_1m_test():
+@pytest.mark.parametrize("with_chain", [False, True])
+def test_adapt_s_norm_10k_enrol_by_1m_test(with_chain):
     """Adaptive S-norm with a 20 000 cohort and the top 300, 10 000 enrolment models x 1 000 000 tests
     (chunks of 65 536 tests): 96 entries spread over the matrix, first and last chunk included,
-    recomputed by the oracle from that pair's enrol-vs-cohort and cohort-vs-test score vectors."""
+    recomputed by the oracle from that pair's enrol-vs-cohort and cohort-vs-test score vectors.
+    with_chain: raw 512-d x-vectors through CentWhiten + LNorm + LDA(200) in the prologue (the
+    configuration as the benchmark runs it); otherwise 200-d length-normalised inputs."""
     from hyperion_amd.backend import PLDABackend
 
     ne, nt, nc, d, K, nbest = 10_000, 1_000_000, 20_000, 200, 150, 300
     model = synth.make_splda(d, K)
     plda = _models()(model)
+    chain = synth.chain_cfg2(d=512, lda_dim=d) if with_chain else None
 
     def unit(n, seed):
+        if with_chain:
+            return _randn(n, 512, seed)
         x = _randn(n, d, seed)
         return x * (d ** 0.5) / x.norm(dim=1, keepdim=True)
 
+    def _host64(t):  # oracle inputs: after the oracle's own chain when there is one
+        a = t.cpu().numpy().astype(np.float64)
+        return O.chain_predict(a, chain) if with_chain else a
+
     xe, xc, xt = unit(ne, 31), unit(nc, 32), unit(nt, 33)
-    be = PLDABackend(plda, None, nbest=nbest, test_chunk=65536)
+    be = PLDABackend(plda, _chain_objects(chain) if with_chain else None, nbest=nbest, test_chunk=65536)
     coh = be.prepare_cohort(xe, xc)
     out = be.score_snorm(xt, coh)
     assert tuple(out.shape) == (ne, nt)
@@ -163,7 +192,7 @@ def test_adapt_s_norm_10k_enrol_by_1m_test():
     ts = np.concatenate([[0, nt - 1, 65_535, 65_536, 983_040], rng.randint(0, nt, 7)])
     ye, yt, yc = _host64(xe[es]), _host64(xt[ts]), _host64(xc)
     ref = O.adapt_s_norm(O.llr_1vs1(model, ye, yt), O.llr_1vs1(model, yc, yt), O.llr_1vs1(model, ye, yc), nbest, 0)
-    got = _host64(out[torch.from_numpy(es).cuda()][:, torch.from_numpy(ts).cuda()])
+    got = out[torch.from_numpy(es).cuda()][:, torch.from_numpy(ts).cuda()].cpu().numpy().astype(np.float64)
     _assert_close(got, ref, tol=2e-5)
 
 

@@ -1,13 +1,17 @@
 #!/usr/bin/env python
 """Summarise a tools/profile.sh output directory into one small text file for profiles/.
 
-    summarize_prof.py <prof dir> <summary.txt> [<workload> <kernel substring> <traffic.json>]
+    summarize_prof.py <prof dir> <summary.txt> [<workload> <kernel substring> <traffic.json>
+                                                [<algorithmic bytes or flops per launch> <peak per second>]]
 
 With the three optional arguments the HBM bytes per launch of the named kernel are written into
 traffic.json under the workload's key: FETCH_SIZE and WRITE_SIZE are reported in KiB; on gfx950
 FETCH_SIZE counts a 128-byte read request as 64 bytes for wide coalesced reads (16 bytes per lane,
 which is what the LDS-DMA and the stationary-row loads of the score kernels are), so it is doubled;
-WRITE_SIZE was calibrated on the score matrix itself (it reports n1 * n2 * 4 bytes exactly)."""
+WRITE_SIZE was calibrated on the score matrix itself (it reports n1 * n2 * 4 bytes exactly).
+With the last two arguments the summary also states the roofline fraction of that kernel recomputed
+from the profiler's own average duration: algorithmic work per launch / average duration / peak --
+the number bench.py's `roofline.frac` (from HIP events in the timed region) has to agree with."""
 import csv
 import glob
 import json
@@ -21,7 +25,7 @@ def find(d, pat):
     return r[0] if r else None
 
 
-def main(d, out, traffic=None):
+def main(d, out, traffic=None, roof=None):
     lines = []
     means = {}
     st = find(os.path.join(d, "trace"), "*kernel_stats.csv")
@@ -33,7 +37,7 @@ def main(d, out, traffic=None):
         for r in rows[:25]:
             lines.append("%-70s %8s %14s %14.1f %8s" % (r["Name"][:70], r["Calls"], r["TotalDurationNs"],
                                                         float(r["AverageNs"]), r["Percentage"]))
-    for tag in ["fetch", "write", "sq"]:
+    for tag in ["fetch", "write", "sq", "sqg"]:
         cc = find(os.path.join(d, tag), "*counter_collection.csv")
         if not cc:
             continue
@@ -66,9 +70,19 @@ def main(d, out, traffic=None):
             lines.append("")
             lines.append("HBM traffic per launch of %s: fetch %.3f GB (x2 corrected), write %.3f GB"
                          % (sub, fetch[0] * 2048 / 1e9, write[0] * 1024 / 1e9))
+    if traffic and roof and st:
+        work, peak = float(roof[0]), float(roof[1])
+        hit = [r for r in rows if traffic[1] in r["Name"]]
+        if hit:
+            avg_s = float(hit[0]["AverageNs"]) * 1e-9
+            lines.append("")
+            lines.append("roofline of %s from this trace: %.6g algorithmic units per launch / %.4f ms average "
+                         "over %s launches = %.6g per s = %.4f of the peak %.6g"
+                         % (traffic[1], work, avg_s * 1e3, hit[0]["Calls"], work / avg_s, work / avg_s / peak, peak))
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3:6] if len(sys.argv) >= 6 else None)
+    main(sys.argv[1], sys.argv[2], sys.argv[3:6] if len(sys.argv) >= 6 else None,
+         sys.argv[6:8] if len(sys.argv) >= 8 else None)
