@@ -78,6 +78,28 @@ class PLDABackend:
         # set to a list to record (stage, start event, end event, shape) of every launch group on the
         # stream it runs on (bench.py: live kernel durations inside the timed step)
         self.trace = None
+        self.topk_counters = None
+        self._skipped_reported = 0
+
+    def topk_report(self):
+        """(rows whose top-k boundary was re-decided from float64 scores, rows where that was given
+        up) since this object was made.  A skipped row has more than 64 cohort scores that fp32 cannot
+        tell from the boundary score (dense or quantised cohort scores): its selection follows the
+        fp32 tie order and may differ from a float64 ranking.  Synchronises with the device."""
+        if self.topk_counters is None:
+            return 0, 0
+        a, b = (int(v) for v in self.topk_counters.cpu())
+        return a, b
+
+    def _warn_skipped(self):
+        skipped = self.topk_report()[1]
+        if skipped > self._skipped_reported:
+            import warnings
+
+            warnings.warn("adaptive S-norm: %d cohort selection(s) have more than 64 scores inside the fp32 "
+                          "uncertainty band of the top-k boundary and were not re-decided in float64; those "
+                          "rows follow the fp32 tie order" % (skipped - self._skipped_reported), RuntimeWarning)
+            self._skipped_reported = skipped
 
     def _timed(self, name, fn, shape=None):
         if self.trace is None:
@@ -115,9 +137,17 @@ class PLDABackend:
         counts = [8 * (shard_range(ne, r, world)[1] - shard_range(ne, r, world)[0]) for r in range(world)]
         lo, hi = shard_range(ne, rank, world)
         exact, coh64 = None, None
+        if self.exact_topk and self.topk_counters is None:
+            import torch
+
+            # [0] rows whose boundary was re-decided in float64, [1] rows where that was given up (more
+            # than 64 cohort scores inside the fp32 uncertainty band of the boundary: those rows keep
+            # the fp32 tie order); totals over the life of this object, see topk_report()
+            self.topk_counters = torch.zeros(2, dtype=torch.int64, device="cuda")
         if self.exact_topk:
             Gc64, bc = self.plan.prologue_f64(engine.upload64(x_cohort), SIDE_TEST)
-            coh64 = {"G_coh": Gc64, "coh_gmax": float(bc[:, 0].max()), "coh_qmax": float(bc[:, 1].max())}
+            coh64 = {"G_coh": Gc64, "coh_gmax": float(bc[:, 0].max()), "coh_qmax": float(bc[:, 1].max()),
+                     "counters_dev": self.topk_counters}
             xe64 = engine.upload64(x_enrol[lo:hi])
             Ge64, be = self.plan.prologue_f64(xe64, SIDE_ENROL)
             exact = dict(coh64, G_rows=Ge64, bnd_rows=be)
@@ -172,4 +202,6 @@ class PLDABackend:
                 engine._ptr(it), ldt, engine._ptr(dst), dst.stride(0), engine.stream_ptr())))
             if reduce is not None:
                 reduce(c0, dst)
+        if self.exact_topk:
+            self._warn_skipped()  # one read of two counters per call
         return out

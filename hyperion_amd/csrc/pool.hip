@@ -51,17 +51,20 @@ __global__ __launch_bounds__(256) void pool_rows_kernel(const TI* __restrict__ x
 //   g_k = (s_k + shift_t[k]) * scale_t[k],  h_k = (s_k + shift_n[k]) * scale_n[k],
 //   q = (|g|^2 - |h|^2) / 2,  packed row = [g, q, 1] or [g, 1, q + c].
 // rows == nullptr means rows 0..n-1 of s; otherwise row i of the output comes from s[rows[i]].
-__global__ __launch_bounds__(256) void book_pack_kernel(const float* __restrict__ s, int64_t lds_, int K,
+// T = double: statistics and maps in float64 (classes of many segments: |g|^2 - |h|^2 cancels to
+// about 1 / count of either term, which fp32 maps cannot carry).
+template <typename T>
+__global__ __launch_bounds__(256) void book_pack_kernel(const T* __restrict__ s, int64_t lds_, int K,
                                                         const int32_t* __restrict__ rows, int64_t n,
-                                                        const float* __restrict__ shift_t,
-                                                        const float* __restrict__ scale_t,
-                                                        const float* __restrict__ shift_n,
-                                                        const float* __restrict__ scale_n, int side,
+                                                        const T* __restrict__ shift_t,
+                                                        const T* __restrict__ scale_t,
+                                                        const T* __restrict__ shift_n,
+                                                        const T* __restrict__ scale_n, int side,
                                                         double c, float* __restrict__ G, int KP) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
-    const float* src = s + (rows ? (int64_t)rows[i] : i) * lds_;
+    const T* src = s + (rows ? (int64_t)rows[i] : i) * lds_;
     float* g = G + i * KP;
     double sg = 0.0, sh = 0.0;
     for (int k = lane; k < K; k += 64) {
@@ -147,7 +150,21 @@ extern "C" int hypmi_book_pack(const float* s, int64_t lds_, int K, const int32_
     HYPMI_REQUIRE(K > 0 && kp >= K + 2 && kp % 8 == 0 && lds_ >= K && n >= 0, "book_pack: bad shape");
     HYPMI_REQUIRE(side == HYPMI_SIDE_ENROL || side == HYPMI_SIDE_TEST, "book_pack: bad side");
     if (n == 0) return HYPMI_OK;
-    hipLaunchKernelGGL(book_pack_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0,
+    hipLaunchKernelGGL(book_pack_kernel<float>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), s, lds_, K, rows, n, shift_t, scale_t, shift_n,
+                       scale_n, side, c, G, kp);
+    HYPMI_HIP(hipGetLastError());
+    return HYPMI_OK;
+}
+
+extern "C" int hypmi_book_pack_f64(const double* s, int64_t lds_, int K, const int32_t* rows, int64_t n,
+                                   const double* shift_t, const double* scale_t, const double* shift_n,
+                                   const double* scale_n, int side, double c, float* G, int kp, void* stream) {
+    HYPMI_REQUIRE(s && shift_t && scale_t && shift_n && scale_n && G, "book_pack_f64: null pointer");
+    HYPMI_REQUIRE(K > 0 && kp >= K + 2 && kp % 8 == 0 && lds_ >= K && n >= 0, "book_pack_f64: bad shape");
+    HYPMI_REQUIRE(side == HYPMI_SIDE_ENROL || side == HYPMI_SIDE_TEST, "book_pack_f64: bad side");
+    if (n == 0) return HYPMI_OK;
+    hipLaunchKernelGGL(book_pack_kernel<double>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), s, lds_, K, rows, n, shift_t, scale_t, shift_n,
                        scale_n, side, c, G, kp);
     HYPMI_HIP(hipGetLastError());

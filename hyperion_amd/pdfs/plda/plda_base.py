@@ -567,6 +567,20 @@ class PLDABase(HypModel):
         for D in (D1, D2):
             N = np.asarray(D[0], dtype=np.float64)
             F = D[1]
+            lds_ = engine.round_up(K, 4)
+            if not isinstance(F, torch.Tensor):
+                # Host statistics arrive in float64 (the reference centres them in float64,
+                # splda.py:326-327): project them in float64 so that F - N mu does not cancel in fp32,
+                # and round only the projected statistics.
+                F64 = np.ascontiguousarray(F, dtype=np.float64)
+                n, d = F64.shape
+                s = torch.zeros((max(n, 1), K), dtype=torch.float64, device="cuda")
+                if n:
+                    aug64 = np.concatenate([F64, N[:, None]], axis=1)
+                    W64 = np.concatenate([bf["P"].T, np.asarray(bf["row_bias"], dtype=np.float64)[:, None]], axis=1)
+                    engine.gemm64(engine.upload64(aug64), engine.upload64(W64), out=s[:n])
+                sides.append((N, s))
+                continue
             F_dev = engine.upload(F)
             n, d = F_dev.shape
             # s = [F | N] [P ; row_bias]: one affine map with the class size as an extra input
@@ -578,7 +592,6 @@ class PLDABase(HypModel):
             Wt[:, :d] = bf["P"].T
             Wt[:, d] = bf["row_bias"]
             Wt_dev = torch.from_numpy(Wt).to(F_dev.device)
-            lds_ = engine.round_up(K, 4)
             s = torch.zeros((n, lds_), dtype=torch.float32, device=F_dev.device)
             if n:
                 _lib.check(lib.hypmi_affine(engine._ptr(aug), n, ld, d + 1, engine._ptr(Wt_dev), ld,
@@ -587,28 +600,29 @@ class PLDABase(HypModel):
         (N1, s1), (N2, s2) = sides
         lam = bf["lam"]
 
-        def vec(a):
-            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+        def vec(a, like=None):  # a map in the precision of the statistics it is applied to
+            dt = np.float64 if like is not None and like.dtype == torch.float64 else np.float32
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).cuda()
 
-        shift_t, shift_n = vec(bf["shift_t"]), vec(bf["shift_n"])
         u1, u2 = np.unique(N1), np.unique(N2)
         single = len(u1) == 1 and len(u2) == 1
         for a in u1:
             i = np.where(N1 == a)[0].astype(np.int32)
             for b in u2:
                 j = np.where(N2 == b)[0].astype(np.int32)
-                sc_t = vec(1.0 / np.sqrt(1.0 + (a + b) * lam))
                 logL = lambda n: float(np.sum(np.log1p(n * lam)))  # noqa: E731
                 c = 0.5 * (logL(a) + logL(b) - logL(a + b)) + bf["c_extra"]
                 Gs = []
                 for (own, rows, s, side) in ((a, i, s1, SIDE_ENROL), (b, j, s2, SIDE_TEST)):
-                    sc_n = vec(1.0 / np.sqrt(1.0 + own * lam))
+                    sc_t = vec(1.0 / np.sqrt(1.0 + (a + b) * lam), s)
+                    sc_n = vec(1.0 / np.sqrt(1.0 + own * lam), s)
+                    sh_t, sh_n = vec(bf["shift_t"], s), vec(bf["shift_n"], s)  # alive until the launch
                     G = torch.empty((len(rows), kp), dtype=torch.float32, device="cuda")
                     r_dev = torch.from_numpy(rows).cuda()
-                    _lib.check(lib.hypmi_book_pack(engine._ptr(s), s.stride(0), K, engine._ptr(r_dev),
-                                                   len(rows), engine._ptr(shift_t), engine._ptr(sc_t),
-                                                   engine._ptr(shift_n), engine._ptr(sc_n), side, c,
-                                                   engine._ptr(G), kp, engine.stream_ptr()))
+                    pack = lib.hypmi_book_pack_f64 if s.dtype == torch.float64 else lib.hypmi_book_pack
+                    _lib.check(pack(engine._ptr(s), s.stride(0), K, engine._ptr(r_dev), len(rows),
+                                    engine._ptr(sh_t), engine._ptr(sc_t), engine._ptr(sh_n), engine._ptr(sc_n), side, c,
+                                    engine._ptr(G), kp, engine.stream_ptr()))
                     Gs.append((G, r_dev))
                 if single:
                     engine.score(Gs[0][0], Gs[1][0], out=out[:, :n2])

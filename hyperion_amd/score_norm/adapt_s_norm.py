@@ -12,7 +12,9 @@ def topk_rows(A, k, discard, exact=None):
     exact: optional source of float64 values used to re-decide members that fp32 cannot separate
     from a selection boundary: {"A64": float64 device matrix A was rounded from} or
     {"G_rows", "G_coh", "bnd_rows", "coh_gmax", "coh_qmax"} (fp64 packed rows of Plan.prologue_f64).
-    With exact["count"] = True the dict receives "counters" = (rows re-decided, rows skipped)."""
+    With exact["count"] = True the dict receives "counters" = (rows re-decided, rows skipped);
+    exact["counters_dev"], a device int64[2], is added to instead and never read here (no host
+    synchronisation: for callers that look at the totals once at the end)."""
     import ctypes
 
     torch = engine.require_gpu()
@@ -25,7 +27,9 @@ def topk_rows(A, k, discard, exact=None):
     ex_ptr, counters = None, None
     if exact is not None:
         ex = _lib.TopkExact()
-        if exact.get("count"):
+        if exact.get("counters_dev") is not None:
+            ex.counters = exact["counters_dev"].data_ptr()
+        elif exact.get("count"):
             counters = torch.zeros(2, dtype=torch.int64, device=A.device)
             ex.counters = counters.data_ptr()
         if "A64" in exact:
@@ -132,11 +136,20 @@ class AdaptSNorm(ScoreNorm):
         # roundings collide at a selection boundary are re-decided from the float64 values
         exact_ec = exact_tc = None
         if m_ec is None and not isinstance(scores_enr_coh, torch.Tensor):
-            exact_ec = {"A64": engine.upload64(scores_enr_coh)}
+            exact_ec = {"A64": engine.upload64(scores_enr_coh), "count": True}
         if m_tc is None and not isinstance(scores_coh_test, torch.Tensor):
-            exact_tc = {"A64": engine.upload64(scores_coh_test).t().contiguous()}
+            exact_tc = {"A64": engine.upload64(scores_coh_test).t().contiguous(), "count": True}
         out = adapt_s_norm_device(S, EC, transpose(CT), self.nbest, self.nbest_discard, m_ec, m_tc,
                                   exact_ec=exact_ec, exact_tc=exact_tc)
+        skipped = sum(e["counters"][1] for e in (exact_ec, exact_tc) if e is not None and "counters" in e)
+        if skipped:
+            import warnings
+
+            # more than 64 cohort scores tie with a selection boundary in fp32 (dense or quantised
+            # scores): those rows keep the fp32 tie order instead of the float64 ranking
+            warnings.warn("AdaptSNorm: %d cohort selection(s) could not be re-decided from the float64 scores "
+                          "(more than 64 scores inside the fp32 uncertainty band of the boundary)" % skipped,
+                          RuntimeWarning)
         if isinstance(scores, torch.Tensor):
             return out
         return engine.to_host(out, float_cpu())

@@ -211,6 +211,13 @@ int hypmi_book_pack(const float* s, int64_t lds, int K, const int32_t* rows, int
                     const float* shift_t, const float* scale_t, const float* shift_n,
                     const float* scale_n, int side, double c, float* G, int kp, void* stream);
 
+/* The same from float64 statistics and float64 maps (same reference lines): for classes of many
+ * segments |g|^2 - |h|^2 cancels to about 1 / count of either term, which needs the maps in double;
+ * g is rounded to fp32 once, q is taken from the rounded g and the double h. */
+int hypmi_book_pack_f64(const double* s, int64_t lds, int K, const int32_t* rows, int64_t n,
+                        const double* shift_t, const double* scale_t, const double* shift_n,
+                        const double* scale_n, int side, double c, float* G, int kp, void* stream);
+
 /* out[ri[a], ci[b]] = blk[a, b]: the `scores[np.ix_(i, j)] = scores_ij` of splda.py:376. */
 int hypmi_scatter_block(const float* blk, int64_t ldb, const int32_t* ri, int64_t nr, const int32_t* ci,
                         int64_t nc, float* out, int64_t ldo, void* stream);

@@ -122,6 +122,32 @@ def test_nvsm_from_stats(golden, kind):
     assert np.array_equal(F1, F1c)
 
 
+def test_book_large_counts_and_offset_mean():
+    """By-the-book scoring from host statistics of classes with about a thousand segments and a model
+    mean far from the origin (|mu| = 40 x the spread): the centring F - N mu is done in float64
+    and the per-count maps are applied in float64 as in the reference (splda.py:326-375).  What is left
+    is the fp32 packed row itself: with a thousand segments a side |q| reaches several thousand while
+    the score is of order ten, and q is carried in fp32 (2^-24 relative), so the bound here is 1e-3 of
+    max(|score|, 1) rather than 1e-4 (no float64 refinement pass exists for by-the-book scoring).
+    Against the oracle (the reference's test data hold no such case: parity pinned by the oracle only)."""
+    import synth
+
+    m = synth.make_splda(48, 10)
+    m = dict(m, mu=np.full(48, 40.0))
+    rng = np.random.RandomState(8)
+    n1, n2 = 6, 9
+    cnt1 = rng.randint(900, 1100, n1)
+    cnt2 = np.array([1, 1, 2, 1, 3, 1, 1, 2, 1])
+    ids1, ids2 = np.repeat(np.arange(n1), cnt1), np.repeat(np.arange(n2), cnt2)
+    x1 = synth.sample_splda(m, n1 + n2, 1, seed=9)[:n1][ids1] + 0.7 * rng.randn(len(ids1), 48)
+    x2 = synth.sample_splda(m, n1 + n2, 1, seed=9)[n1:][ids2] + 0.7 * rng.randn(len(ids2), 48)
+    N1, F1, _ = O.compute_stats_hard(x1, ids1)
+    N2, F2, _ = O.compute_stats_hard(x2, ids2)
+    ref = O.llr_NvsM_book(m, (N1.copy(), F1.copy(), None), (N2.copy(), F2.copy(), None))
+    s = make("splda", m).llr_NvsM((N1, F1, None), (N2, F2, None), method="book")
+    assert_scores(s, ref, rtol=1e-3)
+
+
 def test_compute_stats_hard(golden):
     from hyperion_amd.pdfs.plda import SPLDA
 
@@ -733,3 +759,27 @@ def test_scores_agree_with_the_trainable_layer_formula(golden):
         bb = a if b is None else b
         got = model.llr_NvsM(a, bb, ids1=np.arange(len(a)), ids2=np.arange(len(bb)), method="vavg-lnorm")
         assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_adapt_s_norm_warns_when_boundary_is_not_redecided():
+    """More than 64 cohort scores that fp32 cannot tell from the top-k boundary: the float64 re-decision
+    is given up for that row and the caller is told (the result then follows the fp32 tie order)."""
+    import warnings
+
+    from hyperion_amd.score_norm import AdaptSNorm
+
+    rng = np.random.RandomState(2)
+    ne, nt, nc = 4, 5, 400
+    sc = rng.randn(ne, nt)
+    ct = rng.randn(nc, nt)
+    ec = rng.randn(ne, nc)
+    ec[1, :200] = 3.0 + 1e-9 * rng.randn(200)  # 200 scores equal in fp32, distinct in float64, across the boundary
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        AdaptSNorm(nbest=100).predict(sc, ct, ec)
+    assert any("could not be re-decided" in str(x.message) for x in w)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        AdaptSNorm(nbest=100).predict(sc, ct, rng.randn(ne, nc))
+    assert not any("could not be re-decided" in str(x.message) for x in w)
