@@ -223,7 +223,8 @@ __global__ __launch_bounds__(256, (KS2 <= (NP == 3 ? 5 : 7) ? 2 : 1)) void score
                                                              const uint4* __restrict__ H2,
                                                              float* __restrict__ S, int64_t n1,
                                                              int64_t n2, int64_t ldo,
-                                                             int tiles_per_chunk) {
+                                                             int tiles_per_chunk, int gx, int64_t n_wg,
+                                                             int64_t wg_per_xcd) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef SplitFmt<NP> Fmt;
     typedef typename Fmt::vec vec_t;
@@ -236,11 +237,20 @@ __global__ __launch_bounds__(256, (KS2 <= (NP == 3 ? 5 : 7) ? 2 : 1)) void score
     constexpr int NPW = (PIECES + 3) / 4;           // pieces per wave
     extern __shared__ __attribute__((aligned(16))) uint4 tile[];  // 2 * BUF_SLOTS (up to 128 KiB)
 
+    // Workgroup -> (enrol block bx, test chunk by).  The (chunk, block) pairs are numbered chunk-major
+    // and cut into eight equal contiguous ranges; workgroups are handed to the eight XCDs round robin
+    // (a placement that is assumed for speed only), so launch slot w works on entry w / 8 of range
+    // w % 8: the workgroups that run on one XCD at a time read the same chunk of test rows, which
+    // then crosses the fabric once instead of once per XCD.
+    const int64_t t_wg = (int64_t)(blockIdx.x & 7) * wg_per_xcd + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= wg_per_xcd || t_wg >= n_wg) return;
+    const int bx = (int)(t_wg % gx);
+    const int64_t by = t_wg / gx;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
     const int my_slot = (kq & 1) * HS + NP * (kq >> 1);  // + 2 * NP * ks + s
-    const int64_t i0 = (int64_t)blockIdx.x * (64 * RT) + wave * (16 * RT);
+    const int64_t i0 = (int64_t)bx * (64 * RT) + wave * (16 * RT);
 
     // stationary operand: a[rt][s][ks] = part s of H1[i0 + 16 rt + r16], coordinates 32 ks + 8 kq .. + 7
     vec_t a[RT][NP][KS2];
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(256, (KS2 <= (NP == 3 ? 5 : 7) ? 2 : 1)) void score
         }
     }
 
-    const int64_t tile0 = (int64_t)blockIdx.y * tiles_per_chunk;
+    const int64_t tile0 = by * tiles_per_chunk;
     const int64_t ntiles_all = (n2 + 31) / 32;
     int ntiles = tiles_per_chunk;
     if (tile0 + ntiles > ntiles_all) ntiles = (int)(ntiles_all - tile0);
@@ -347,7 +357,15 @@ __global__ __launch_bounds__(256, (KS2 <= (NP == 3 ? 5 : 7) ? 2 : 1)) void score
 #pragma unroll
                     for (int e = 0; e < 4; ++e) hi[rt][ct][e] = mid[rt][ct][e] = lo[rt][ct][e] = 0.f;
 
-            // bt[(16 ct) * ROW_SLOTS + 2 NP ks + s]: part s of test row 16 ct + r16, this lane's chunk of k-step ks
+            // bt[(16 ct) * ROW_SLOTS + 2 NP ks + s]: part s of test row 16 ct + r16, this lane's chunk of k-step ks.
+            // The lane's position is taken afresh from the lane counter here (two instructions per tile):
+            // kept in a register across the tile loop it is the value the register allocator spills at
+            // 256 registers, and the reload's wait would drain the previous tile's stores before the
+            // first MFMA of every tile.
+            unsigned ln;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+            const int r16 = (int)(ln & 15u), kq = (int)(ln >> 4);
+            const int my_slot = (kq & 1) * HS + NP * (kq >> 1);
             const uint4* bt = tile + buf * BUF_SLOTS + r16 * ROW_SLOTS + my_slot;
             vec_t b[NP];
 #pragma unroll
@@ -433,6 +451,7 @@ __global__ __launch_bounds__(256, (KS2 <= (NP == 3 ? 5 : 7) ? 2 : 1)) void score
             }
 
             if constexpr (!ST) {
+                const int c32 = (int)(ln & 31u), u = (int)(ln >> 5);
                 const int64_t col = (tile0 + it) * 32 + c32;
                 const int64_t rows_left = n1 - i0;  // wave-uniform
                 if (col < n2) {
@@ -470,8 +489,10 @@ static int launch_split(const uint4* H1, int64_t n1, const uint4* H2, int64_t n2
     if (LDS_BYTES > 48 * 1024)
         HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_split_kernel<NP, KS2, RT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    hipLaunchKernelGGL((score_split_kernel<NP, KS2, RT>), dim3((unsigned)g.gx, (unsigned)g.gy), dim3(256), LDS_BYTES,
-                       stream, H1, H2, S, n1, n2, lds, g.tiles_per_chunk);
+    const int64_t n_wg = g.gx * g.gy, wg_per_xcd = (n_wg + 7) / 8;
+    HYPMI_REQUIRE(g.gx <= 0x7fffffffLL && 8 * wg_per_xcd <= 0x7fffffffLL, "score: too many workgroups");
+    hipLaunchKernelGGL((score_split_kernel<NP, KS2, RT>), dim3((unsigned)(8 * wg_per_xcd)), dim3(256), LDS_BYTES,
+                       stream, H1, H2, S, n1, n2, lds, g.tiles_per_chunk, (int)g.gx, n_wg, wg_per_xcd);
     HYPMI_HIP(hipGetLastError());
     return HYPMI_OK;
 }

@@ -49,9 +49,11 @@ struct LaunchGeom {
 static int launch_geometry(int64_t n1, int64_t n2, int rows_per_wg, LaunchGeom* g) {
     const int64_t gx = (n1 + rows_per_wg - 1) / rows_per_wg;
     const int64_t ntiles = (n2 + 31) / 32;
-    // 128 tiles (4096 test rows) per stream: measured on 100k x 100k, K = 150, fp16 pairs (median of 7):
-    // 32 tiles 9.53 ms, 64 9.27-9.32, 128 9.10, 256 9.12, 512 9.74 (too few workgroups for an even last wave)
-    int64_t tiles_per_chunk = 128;
+    // 64 tiles (2048 test rows, 1.7 MB of fp16 pairs: half an XCD's L2) per stream.  Measured on
+    // 100k x 100k, K = 150, fp16 pairs, with the chunk-major workgroup order of the split kernel:
+    // 32 tiles 9.61 ms, 64 9.34, 128 9.45, 256 9.64 (the kernel is bound by its stores and the clock it
+    // holds, not by these re-reads: 3.7 GB of L2 misses per launch at 128 tiles against 40 GB written)
+    int64_t tiles_per_chunk = 64;
     while (tiles_per_chunk > 8 && gx * ((ntiles + tiles_per_chunk - 1) / tiles_per_chunk) < 2048)
         tiles_per_chunk /= 2;
     int64_t gy = (ntiles + tiles_per_chunk - 1) / tiles_per_chunk;
