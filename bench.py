@@ -364,9 +364,10 @@ def score_matrix_stage(plda, preproc, n=100_000, reps=3):
         for it in range(reps + 1):
             e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             e[0].record()
-            G1, G2 = plan.prologue(x1, SIDE_ENROL), plan.prologue(x2, SIDE_TEST)
-            if fmt:
-                G1, G2 = engine.split_rows(G1, fmt), engine.split_rows(G2, fmt)
+            if fmt:  # one kernel per side: chain, projection, packing and the fp16-pair conversion
+                G1, G2 = plan.prologue_split(x1, SIDE_ENROL, fmt), plan.prologue_split(x2, SIDE_TEST, fmt)
+            else:
+                G1, G2 = plan.prologue(x1, SIDE_ENROL), plan.prologue(x2, SIDE_TEST)
             e[1].record()
             engine.score(G1, G2, out=S, split=False)
             e[2].record()
@@ -488,10 +489,10 @@ def main_scores(args, cfg, chain, model, plda, preproc, world, rank, dist):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
         if record:
             ev[0].record()
-        G1 = plan.prologue(x1, SIDE_ENROL)
-        G2 = plan.prologue(x2, SIDE_TEST)
-        if use_split:  # 16-bit matrix cores at fp32 accuracy
-            G1, G2 = engine.split_rows(G1, fmt), engine.split_rows(G2, fmt)
+        if use_split:  # 16-bit matrix cores at fp32 accuracy (fp16 pairs: made by the prologue kernel itself)
+            G1, G2 = plan.prologue_split(x1, SIDE_ENROL, fmt), plan.prologue_split(x2, SIDE_TEST, fmt)
+        else:
+            G1, G2 = plan.prologue(x1, SIDE_ENROL), plan.prologue(x2, SIDE_TEST)
         if record:
             ev[1].record()
         engine.score(G1, G2, out=S, split=False)

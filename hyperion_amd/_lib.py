@@ -74,6 +74,9 @@ SIGNATURES = {
     "hypmi_prologue_workspace_bytes": (i64, [c_void_p, i64]),
     "hypmi_prologue": (ctypes.c_int, [c_void_p, c_void_p, i64, i64, ctypes.c_int, c_void_p, c_void_p,
                                       i64, c_void_p]),
+    "hypmi_prologue_pairs_supported": (ctypes.c_int, [c_void_p]),
+    "hypmi_prologue_pairs": (ctypes.c_int, [c_void_p, c_void_p, i64, i64, ctypes.c_int, c_void_p, c_void_p,
+                                            c_void_p, i64, c_void_p]),
     "hypmi_prologue_noalloc_max_rows": (i64, [c_void_p]),
     "hypmi_prologue_noalloc": (ctypes.c_int, [c_void_p, c_void_p, i64, i64, ctypes.c_int, c_void_p, c_void_p]),
     "hypmi_transform": (ctypes.c_int, [c_void_p, c_void_p, i64, i64, c_void_p, i64, c_void_p, i64,

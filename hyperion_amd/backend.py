@@ -115,7 +115,7 @@ class PLDABackend:
     # ---- embeddings ---------------------------------------------------------------------------
     def embed(self, x, side):
         """Raw vectors (numpy or device tensor) -> packed device rows for one side of a trial."""
-        return self.plan.prologue(engine.upload(x), side)
+        return self.plan.prologue_split(engine.upload(x), side)
 
     def score(self, x_enrol, x_test, out=None):
         """Raw PLDA log-likelihood ratios, device [n_enrol, n_test]."""
@@ -129,7 +129,7 @@ class PLDABackend:
         global (the only inter-GPU exchange of the whole pipeline)."""
         Ge = self._timed("prologue", lambda: self.embed(x_enrol, SIDE_ENROL))
         xc = engine.upload(x_cohort)
-        Gc_test = self._timed("prologue", lambda: self.plan.prologue(xc, SIDE_TEST))
+        Gc_test = self._timed("prologue", lambda: self.plan.prologue_split(xc, SIDE_TEST))
         A_ec = self._timed("score_enrol_cohort", lambda: engine.score(Ge, Gc_test))
         ne, nc = A_ec.shape
         assert self.nbest_discard < nc
@@ -177,8 +177,8 @@ class PLDABackend:
             c1 = min(nt, c0 + self.test_chunk)
             xc = xt[c0:c1]
             T = self._timed
-            Gt_rows = T("prologue", lambda: self.plan.prologue(xc, SIDE_ENROL))  # tests as rows of the cohort panel
-            Gt_cols = T("prologue", lambda: self.plan.prologue(xc, SIDE_TEST))   # tests as columns of the trial matrix
+            Gt_rows = T("prologue", lambda: self.plan.prologue_split(xc, SIDE_ENROL))  # tests as rows of the cohort panel
+            Gt_cols = T("prologue", lambda: self.plan.prologue_split(xc, SIDE_TEST))   # tests as columns of the trial matrix
             A_tc = T("score_test_cohort", lambda: engine.score(Gt_rows, cohort["Gc_test"]))  # [chunk, cohort]
             exact = None
             if cohort.get("coh64") is not None:

@@ -14,6 +14,7 @@
 
 #include "common.h"
 #include "gemm_tile.h"
+#include "pair_rows.h"
 
 // ------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -337,7 +338,7 @@ __device__ __forceinline__ void fused_v_chunk(const float* __restrict__ x, int64
                                               int64_t n, int n_v, int d_in, float* smem,
                                               const float (&sc)[TM][16], const float* __restrict__ bias_vin,
                                               const float* __restrict__ bias_vout, float* __restrict__ Z,
-                                              int64_t ldz) {
+                                              int64_t ldz, float* zt = nullptr, int zld = 0) {
     f32x16 acc[TM][TN];
     gemm_tile::zero<TM, TN>(acc);
     gemm_tile::mainloop<TM, TN>(x, ldx, Wv, ldw, m0, n0, n, n_v, d_in, smem, acc);
@@ -351,8 +352,10 @@ __device__ __forceinline__ void fused_v_chunk(const float* __restrict__ x, int64
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int64_t row = m0 + gemm_tile::row_of<TM>(i, e);
-                    if (row < n) Z[row * ldz + col] = fmaf(sc[i][e], acc[i][j][e] + bi, bo);
+                    const int lr = gemm_tile::row_of<TM>(i, e);
+                    const float zv = fmaf(sc[i][e], acc[i][j][e] + bi, bo);
+                    if (zt) zt[lr * zld + col] = zv;  // the workgroup's rows stay on the chip
+                    else if (m0 + lr < n) Z[(m0 + lr) * ldz + col] = zv;
                 }
         }
     }
@@ -363,13 +366,27 @@ __device__ __forceinline__ void fused_v_chunk(const float* __restrict__ x, int64
 // chunks, keeping only per-row sums of squares (u never leaves the chip), turns them into the
 // per-row scale, then walks the 2K columns of v = x (A1 A2) + b1 A2 and writes
 // z = scale * v + b2 = [g | h].
-template <int TM>
+// What the PAIRS variant of prologue_fused_kernel does with its rows instead of writing z: the
+// per-column maps and q of the shared-basis form (book_pack_kernel), the packed row [g, q, 1 ...]
+// and its conversion to scaled fp16 pairs (pair_rows_kernel), all on the workgroup's LDS copy of z.
+struct PairTail {
+    const float* col_map;  // shift_t | scale_t | shift_n | scale_n, K floats each
+    int K, KP, side, ks16;
+    double c;
+    uint4* H;   // [n x row_slots] fp16 pairs
+    float* G;   // optional [n x KP] packed fp32 rows (nullptr: not wanted)
+};
+
+template <int TM, bool PAIRS = false>
 __global__ __launch_bounds__(256) void prologue_fused_kernel(
     const float* __restrict__ x, int64_t ldx, int64_t n, int d_in, const float* __restrict__ Wcat,
     int64_t ldw, const float* __restrict__ bias_u, const float* __restrict__ bias_vin,
     const float* __restrict__ bias_vout, int n_u, int n_v, float sqrt_dn, int norm_from_input,
-    float* __restrict__ Z, int64_t ldz) {
+    float* __restrict__ Z, int64_t ldz, PairTail pt) {
     constexpr int BM = 64 * TM;
+    extern __shared__ __attribute__((aligned(16))) float zt_dyn[];  // PAIRS: BM x (KP + 1) floats
+    float* const zt = PAIRS ? zt_dyn : nullptr;
+    const int zld = PAIRS ? pt.KP + 1 : 0;
     __shared__ __attribute__((aligned(16))) float smem[gemm_tile::Shape<TM, 2>::SMEM_FLOATS];
     __shared__ float rowsq[2][BM];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -443,23 +460,109 @@ __global__ __launch_bounds__(256) void prologue_fused_kernel(
     // 128-column chunks; a remainder of at most 64 columns runs as a 64-column chunk
     int n0 = 0;
     for (; n_v - n0 > 64; n0 += 128)
-        fused_v_chunk<TM, 2>(x, ldx, Wv, ldw, m0, n0, n, n_v, d_in, smem, sc, bias_vin, bias_vout, Z, ldz);
+        fused_v_chunk<TM, 2>(x, ldx, Wv, ldw, m0, n0, n, n_v, d_in, smem, sc, bias_vin, bias_vout, Z, ldz, zt, zld);
     if (n0 < n_v)
-        fused_v_chunk<TM, 1>(x, ldx, Wv, ldw, m0, n0, n, n_v, d_in, smem, sc, bias_vin, bias_vout, Z, ldz);
+        fused_v_chunk<TM, 1>(x, ldx, Wv, ldw, m0, n0, n, n_v, d_in, smem, sc, bias_vin, bias_vout, Z, ldz, zt, zld);
+    if constexpr (PAIRS) {
+        using namespace hypmi_detail;
+        const int K = pt.K, KP = pt.KP;
+        const float *shift_t = pt.col_map, *scale_t = pt.col_map + K, *shift_n = pt.col_map + 2 * K,
+                    *scale_n = pt.col_map + 3 * K;
+        __syncthreads();  // every column chunk of the rows is in LDS
+        // (a) the per-column maps and q, one wavefront per row, in the order book_pack_kernel sums
+        for (int rr = wave; rr < BM; rr += 4) {
+            float* z = zt + rr * zld;
+            double sg = 0.0, sh = 0.0;
+            for (int k = lane; k < K; k += 64) {
+                const double v = z[k];
+                const float gv = (float)((v + (double)shift_t[k]) * (double)scale_t[k]);
+                const double hv = (v + (double)shift_n[k]) * (double)scale_n[k];
+                sg += (double)gv * gv;
+                sh += hv * hv;
+                z[k] = gv;
+            }
+            const double q = 0.5 * (wave_sum(sg) - wave_sum(sh));
+            for (int k = K + lane; k < KP; k += 64) {
+                float v = 0.f;
+                if (k == K) v = pt.side == HYPMI_SIDE_ENROL ? (float)q : 1.f;
+                if (k == K + 1) v = pt.side == HYPMI_SIDE_ENROL ? 1.f : (float)(q + pt.c);
+                z[k] = v;
+            }
+        }
+        __syncthreads();
+        // (b) packed row -> scaled fp16 pairs: lane = chunk of eight coordinates
+        const int hs = split_half_slots(pt.ks16, 2), row_slots = split_row_slots(pt.ks16, 2);
+        for (int rr = wave; rr < BM; rr += 4) {
+            const int64_t row = m0 + rr;
+            if (row >= n) break;  // wave-uniform
+            const float* z = zt + rr * zld;
+            const int k0 = 8 * lane;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = k0 < KP ? z[k0 + e] : 0.f;
+            if (pt.G && k0 < KP) {
+                float4* g = reinterpret_cast<float4*>(pt.G + row * KP + k0);
+                g[0] = make_float4(v[0], v[1], v[2], v[3]);
+                g[1] = make_float4(v[4], v[5], v[6], v[7]);
+            }
+            float m = pair_chunk_max(v);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            const int up = pair_scale_exponent(m);
+            uint4* out = pt.H + row * row_slots;
+            if (k0 < 16 * pt.ks16) pair_chunk_store(v, up, lane, hs, out);
+            if (lane == 0) pair_row_tail(up, pt.ks16, hs, row_slots, out);
+        }
+    }
 }
 
 int run_fused_tail(const hypmi_plan* p, const float* in, int64_t ldin, int64_t rows, float* Z, int64_t ldz,
                    hipStream_t stream) {
     const FusedTail& f = p->fused;
     const float* bias_out = p->shared ? p->sfin.bias : p->fin.bias;
+    const PairTail none = {};
     if (rows >= 128 * 2048) {
         hipLaunchKernelGGL(prologue_fused_kernel<2>, dim3((unsigned)((rows + 127) / 128)), dim3(256), 0, stream,
                            in, ldin, rows, f.d_in, f.Wcat, f.ldw, f.bias_u, f.bias_vin, bias_out, f.n_u,
-                           f.n_v, f.sqrt_dn, f.norm_from_input ? 1 : 0, Z, ldz);
+                           f.n_v, f.sqrt_dn, f.norm_from_input ? 1 : 0, Z, ldz, none);
     } else {
         hipLaunchKernelGGL(prologue_fused_kernel<1>, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, stream, in,
                            ldin, rows, f.d_in, f.Wcat, f.ldw, f.bias_u, f.bias_vin, bias_out, f.n_u, f.n_v,
-                           f.sqrt_dn, f.norm_from_input ? 1 : 0, Z, ldz);
+                           f.sqrt_dn, f.norm_from_input ? 1 : 0, Z, ldz, none);
+    }
+    HYPMI_HIP(hipGetLastError());
+    return HYPMI_OK;
+}
+
+// The fused tail with the packing and the fp16-pair conversion in its epilogue (shared-basis plans).
+int run_fused_tail_pairs(const hypmi_plan* p, const float* in, int64_t ldin, int64_t rows, int side, void* H,
+                         float* G, hipStream_t stream) {
+    const FusedTail& f = p->fused;
+    PairTail pt;
+    pt.col_map = p->col_map;
+    pt.K = p->K;
+    pt.KP = p->KP;
+    pt.side = side;
+    pt.ks16 = 2 * ((p->KP + 31) / 32);
+    pt.c = p->c;
+    pt.H = static_cast<uint4*>(H);
+    pt.G = G;
+    const int lds1 = 64 * (p->KP + 1) * (int)sizeof(float), lds2 = 2 * lds1;
+    const bool big = rows >= 128 * 2048 && lds2 <= 96 * 1024;
+    if (big) {
+        if (lds2 > 32 * 1024)
+            HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prologue_fused_kernel<2, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+        hipLaunchKernelGGL((prologue_fused_kernel<2, true>), dim3((unsigned)((rows + 127) / 128)), dim3(256), lds2,
+                           stream, in, ldin, rows, f.d_in, f.Wcat, f.ldw, f.bias_u, f.bias_vin, p->sfin.bias, f.n_u,
+                           f.n_v, f.sqrt_dn, f.norm_from_input ? 1 : 0, nullptr, 0, pt);
+    } else {
+        if (lds1 > 32 * 1024)
+            HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&prologue_fused_kernel<1, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+        hipLaunchKernelGGL((prologue_fused_kernel<1, true>), dim3((unsigned)((rows + 63) / 64)), dim3(256), lds1,
+                           stream, in, ldin, rows, f.d_in, f.Wcat, f.ldw, f.bias_u, f.bias_vin, p->sfin.bias, f.n_u,
+                           f.n_v, f.sqrt_dn, f.norm_from_input ? 1 : 0, nullptr, 0, pt);
     }
     HYPMI_HIP(hipGetLastError());
     return HYPMI_OK;
@@ -656,6 +759,44 @@ int prologue_impl(const hypmi_plan* p, const float* x, int64_t n, int64_t ldx, i
     return HYPMI_OK;
 }
 }  // namespace
+
+extern "C" int hypmi_prologue_pairs_supported(const hypmi_plan* p) {
+    // the fused tail in its shared-basis form, and a packed width the fp16-pair score kernel takes
+    return (p && p->K > 0 && p->fused.enabled && p->shared && p->col_map && p->KP % 8 == 0 && p->KP <= 320) ? 1 : 0;
+}
+
+extern "C" int hypmi_prologue_pairs(const hypmi_plan* p, const float* x, int64_t n, int64_t ldx, int side,
+                                    void* H, float* G, void* ws, int64_t ws_bytes, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HYPMI_REQUIRE(hypmi_prologue_pairs_supported(p),
+                  "prologue_pairs: this plan has no fused shared-basis tail; use hypmi_prologue + hypmi_pair_rows");
+    HYPMI_REQUIRE(x && H, "prologue_pairs: null pointer");
+    HYPMI_REQUIRE(n >= 0 && ldx >= round_up(p->d_in, 4) && ldx % 4 == 0 && aligned16(x) && aligned16(H) &&
+                      (!G || aligned16(G)),
+                  "prologue_pairs: buffers must be 16-byte aligned with ldx %% 4 == 0 and ldx >= d_in rounded up to 4");
+    HYPMI_REQUIRE(side == HYPMI_SIDE_ENROL || side == HYPMI_SIDE_TEST, "prologue_pairs: bad side %d", side);
+    if (n == 0) return HYPMI_OK;
+    Work w;
+    int rc = carve(p, n, ws, ws_bytes, &w);
+    if (rc != HYPMI_OK) return rc;
+    // Nothing in front of the fused tail writes a buffer (the usual chain: one affine step, the length
+    // norm, one more affine step): the rows need no staging and all of them go in one launch.
+    bool staged = false;
+    for (int i = 0; i + 1 < p->n_seg; ++i) staged |= p->seg[i].Wt != nullptr || p->seg[i].lnorm;
+    if (!staged) w.rows = n;
+    const int64_t row_bytes = (int64_t)hypmi_detail::split_row_slots(2 * ((p->KP + 31) / 32), 2) * 16;
+    for (int64_t r0 = 0; r0 < n; r0 += w.rows) {
+        const int64_t rows = (n - r0 < w.rows) ? n - r0 : w.rows;
+        const float* cur;
+        int64_t ldcur;
+        rc = run_segments(p, p->n_seg - 1, x + r0 * ldx, ldx, rows, w, nullptr, 0, &cur, &ldcur, stream);
+        if (rc != HYPMI_OK) return rc;
+        rc = run_fused_tail_pairs(p, cur, ldcur, rows, side, static_cast<char*>(H) + r0 * row_bytes,
+                                  G ? G + r0 * p->KP : nullptr, stream);
+        if (rc != HYPMI_OK) return rc;
+    }
+    return HYPMI_OK;
+}
 
 extern "C" int hypmi_transform(const hypmi_plan* p, const float* x, int64_t n, int64_t ldx, float* y,
                                int64_t ldy, void* ws, int64_t ws_bytes, void* stream_) {

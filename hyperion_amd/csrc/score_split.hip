@@ -40,6 +40,7 @@
 // segments).  The 16x16x32 shape is used because it sustains about 14 % more flop/s than 32x32x16
 // under the chip's power limit, which is what bounds this kernel.
 #include "score_tile.h"
+#include "pair_rows.h"
 #include <type_traits>
 
 namespace hypmi_detail {
@@ -86,12 +87,6 @@ __device__ __forceinline__ void split3(float x, unsigned& b0, unsigned& b1, unsi
     b1 = bf16_rn_bits(r1);
     const float r2 = r1 - __uint_as_float(b1 << 16);
     b2 = bf16_rn_bits(r2);
-}
-
-__host__ __device__ constexpr int split_half_slots(int ks16, int np = 3) { return (np * ks16 + 15) / 16 * 16; }
-// the sum of the two halves is even, so the last slot of a row is always padding
-__host__ __device__ constexpr int split_row_slots(int ks16, int np = 3) {
-    return (split_half_slots(ks16, np) + np * ks16) | 1;
 }
 
 // One thread per (row, chunk pair, half): 8 coordinates -> 3 slots; the first thread of a row also
@@ -153,47 +148,14 @@ __global__ __launch_bounds__(256) void pair_rows_kernel(const float* __restrict_
         v[0] = lo.x, v[1] = lo.y, v[2] = lo.z, v[3] = lo.w;
         v[4] = hi.x, v[5] = hi.y, v[6] = hi.z, v[7] = hi.w;
     }
-    float m = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float a = fabsf(v[e]);
-        if (a <= 3.402823466e38f && a > m) m = a;  // NaN and infinity do not set the scale
-    }
+    float m = pair_chunk_max(v);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    // m = f * 2^ex with f in [0.5, 1): scaling by 2^(15 - ex) puts the maximum in [2^14, 2^15); capped
-    // so that the inverse scale 2^-up stays a normal float (rows below 2^-111 keep fewer bits)
-    int up = m > 0.f ? 15 - __builtin_amdgcn_frexp_expf(m) : 0;
-    if (up > 126) up = 126;
+    const int up = pair_scale_exponent(m);
     const int hs = split_half_slots(ks16, 2), row_slots = split_row_slots(ks16, 2);
     uint4* out = H + row * row_slots;
-    if (k0 < 16 * ks16) {
-        unsigned b[2][8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float x = ldexpf(v[e], up);
-            const _Float16 x0 = (_Float16)x;  // round to nearest even; NaN and infinity keep their class
-            const float r = x - (float)x0;
-            const _Float16 x1 = (r == r && fabsf(r) <= 3.402823466e38f) ? (_Float16)r : (_Float16)0.f;
-            b[0][e] = __builtin_bit_cast(unsigned short, x0);
-            b[1][e] = __builtin_bit_cast(unsigned short, x1);
-        }
-        const int j = lane >> 1, h = lane & 1;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            uint4 w;
-            w.x = b[s][0] | (b[s][1] << 16);
-            w.y = b[s][2] | (b[s][3] << 16);
-            w.z = b[s][4] | (b[s][5] << 16);
-            w.w = b[s][6] | (b[s][7] << 16);
-            out[h * hs + 2 * j + s] = w;
-        }
-    }
-    if (lane == 0) {
-        for (int p = 2 * ks16; p < hs; ++p) out[p] = make_uint4(0, 0, 0, 0);
-        for (int p = hs + 2 * ks16; p < row_slots - 1; ++p) out[p] = make_uint4(0, 0, 0, 0);
-        out[row_slots - 1] = make_uint4(__float_as_uint(ldexpf(1.f, -up)), 0, 0, 0);
-    }
+    if (k0 < 16 * ks16) pair_chunk_store(v, up, lane, hs, out);
+    if (lane == 0) pair_row_tail(up, ks16, hs, row_slots, out);
 }
 
 // LDS-DMA piece with a wave-uniform source: lane copies the 16 bytes at sbase + voff to LDS address

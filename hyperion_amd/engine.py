@@ -310,6 +310,30 @@ class Plan:
                                             _ptr(ws), nbytes, stream_ptr()))
         return G
 
+    def prologue_split(self, x, side, fmt=None, keep_rows=False):
+        """x -> the operand of the 16-bit score kernels (SplitRows).  Plans with a fused shared-basis
+        tail and the default fp16-pair format do it in the prologue kernel itself (one launch, the
+        packed fp32 rows never reach memory unless keep_rows asks for them too: then (split, G)
+        is returned); other plans, formats or widths convert the packed rows in a second kernel."""
+        torch = _torch()
+        fmt = fmt or DEFAULT_SPLIT
+        self._check_x(x)
+        n = x.shape[0]
+        if fmt == "pair" and n and self._lib.hypmi_prologue_pairs_supported(self._h):
+            H = torch.empty(self._lib.hypmi_pair_bytes(self.kp, n) // 4, dtype=torch.int32, device=x.device)
+            G = torch.empty((n, self.kp), dtype=torch.float32, device=x.device) if keep_rows else None
+            ws, nbytes = self._workspace(n)
+            _lib.check(self._lib.hypmi_prologue_pairs(self._h, _ptr(x), n, x.stride(0), int(side), _ptr(H),
+                                                      _ptr(G) if keep_rows else None, _ptr(ws), nbytes,
+                                                      stream_ptr()))
+            split = SplitRows(H, n, self.kp, fmt)
+            return (split, G) if keep_rows else split
+        G = self.prologue(x, side)
+        split = split_rows(G, fmt)
+        if split is None:  # no 16-bit kernel for this width: the fp32 rows are the operand
+            return (G, G) if keep_rows else G
+        return (split, G) if keep_rows else split
+
     def prologue_f64(self, x64, side):
         """x64: device float64 [n, d_in] -> (G64 [n, K + 2] rows [g, q(+c), |g|], bnd [n, 2] floats)."""
         torch = _torch()

@@ -783,3 +783,35 @@ def test_adapt_s_norm_warns_when_boundary_is_not_redecided():
         warnings.simplefilter("always")
         AdaptSNorm(nbest=100).predict(sc, ct, rng.randn(ne, nc))
     assert not any("could not be re-decided" in str(x.message) for x in w)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,lda,K,n", [(512, 200, 150, 1000), (512, 200, 150, 64), (96, 40, 12, 333), (99, 37, 10, 1)])
+def test_prologue_pairs_equals_prologue_then_pair_rows(d, lda, K, n):
+    """The prologue kernel that writes fp16 pairs itself against the same plan's packed rows converted
+    by the stand-alone kernel: the pairs, the inverse scales and the optional packed rows, bit for
+    bit, on both sides of a trial, rows that do not fill the last workgroup included."""
+    import torch
+
+    import synth
+    from hyperion_amd import _lib, engine
+    from hyperion_amd.engine import SIDE_ENROL, SIDE_TEST
+    from hyperion_amd.pdfs.plda import SPLDA
+    from hyperion_amd.transforms import LDA, CentWhiten, LNorm, TransformList
+
+    chain = synth.chain_cfg2(d=d, lda_dim=lda, seed=4)
+    m = synth.make_splda(lda, K)
+    tl = TransformList([CentWhiten(mu=chain[0][1], T=chain[0][2], name="cw"), LNorm(name="ln"),
+                        LDA(mu=chain[2][1], T=chain[2][2], name="lda")])
+    plan = SPLDA(mu=m["mu"], V=m["V"], W=m["W"]).score_plan(tl)
+    assert _lib.load().hypmi_prologue_pairs_supported(plan._h) == 1
+    x = engine.upload(np.random.RandomState(n).randn(n, d).astype(np.float32) * 2)
+    for side in (SIDE_ENROL, SIDE_TEST):
+        G = plan.prologue(x, side)
+        want = engine.split_rows(G, "pair")
+        got, G2 = plan.prologue_split(x, side, keep_rows=True)
+        nb = _lib.load().hypmi_pair_row_bytes(plan.kp) * n // 4
+        assert torch.equal(got.H[:nb], want.H[:nb])
+        assert torch.equal(G2, G)
+        got_only = plan.prologue_split(x, side)
+        assert torch.equal(got_only.H[:nb], want.H[:nb])
