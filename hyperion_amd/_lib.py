@@ -76,7 +76,7 @@ SIGNATURES = {
                                       i64, c_void_p]),
     "hypmi_prologue_pairs_supported": (ctypes.c_int, [c_void_p]),
     "hypmi_prologue_pairs": (ctypes.c_int, [c_void_p, c_void_p, i64, i64, ctypes.c_int, c_void_p, c_void_p,
-                                            c_void_p, i64, c_void_p]),
+                                            c_void_p, c_void_p, i64, c_void_p]),
     "hypmi_prologue_noalloc_max_rows": (i64, [c_void_p]),
     "hypmi_prologue_noalloc": (ctypes.c_int, [c_void_p, c_void_p, i64, i64, ctypes.c_int, c_void_p, c_void_p]),
     "hypmi_transform": (ctypes.c_int, [c_void_p, c_void_p, i64, i64, c_void_p, i64, c_void_p, i64,

@@ -177,8 +177,8 @@ class PLDABackend:
             c1 = min(nt, c0 + self.test_chunk)
             xc = xt[c0:c1]
             T = self._timed
-            Gt_rows = T("prologue", lambda: self.plan.prologue_split(xc, SIDE_ENROL))  # tests as rows of the cohort panel
-            Gt_cols = T("prologue", lambda: self.plan.prologue_split(xc, SIDE_TEST))   # tests as columns of the trial matrix
+            # tests as rows of the cohort panel and as columns of the trial matrix
+            Gt_rows, Gt_cols = T("prologue", lambda: self.plan.prologue_split_both(xc))
             A_tc = T("score_test_cohort", lambda: engine.score(Gt_rows, cohort["Gc_test"]))  # [chunk, cohort]
             exact = None
             if cohort.get("coh64") is not None:

@@ -373,8 +373,9 @@ struct PairTail {
     const float* col_map;  // shift_t | scale_t | shift_n | scale_n, K floats each
     int K, KP, side, ks16;
     double c;
-    uint4* H;   // [n x row_slots] fp16 pairs
-    float* G;   // optional [n x KP] packed fp32 rows (nullptr: not wanted)
+    uint4* H;        // [n x row_slots] fp16 pairs of side `side`
+    uint4* H_other;  // optional: the same rows packed for the other side of a trial
+    float* G;        // optional [n x KP] packed fp32 rows of side `side` (nullptr: not wanted)
 };
 
 template <int TM, bool PAIRS = false>
@@ -482,37 +483,44 @@ __global__ __launch_bounds__(256) void prologue_fused_kernel(
                 z[k] = gv;
             }
             const double q = 0.5 * (wave_sum(sg) - wave_sum(sh));
-            for (int k = K + lane; k < KP; k += 64) {
-                float v = 0.f;
-                if (k == K) v = pt.side == HYPMI_SIDE_ENROL ? (float)q : 1.f;
-                if (k == K + 1) v = pt.side == HYPMI_SIDE_ENROL ? 1.f : (float)(q + pt.c);
-                z[k] = v;
-            }
+            // coordinates K, K + 1 depend on the side ([q, 1] or [1, q + c]): both q's are kept, the
+            // test side's in the spare column behind the row
+            for (int k = K + lane; k <= KP; k += 64) z[k] = k == K ? (float)q : (k == KP ? (float)(q + pt.c) : 0.f);
         }
         __syncthreads();
         // (b) packed row -> scaled fp16 pairs: lane = chunk of eight coordinates
         const int hs = split_half_slots(pt.ks16, 2), row_slots = split_row_slots(pt.ks16, 2);
-        for (int rr = wave; rr < BM; rr += 4) {
-            const int64_t row = m0 + rr;
-            if (row >= n) break;  // wave-uniform
-            const float* z = zt + rr * zld;
-            const int k0 = 8 * lane;
-            float v[8];
+        auto emit = [&](int side, uint4* H, float* G) {
+            for (int rr = wave; rr < BM; rr += 4) {
+                const int64_t row = m0 + rr;
+                if (row >= n) break;  // wave-uniform
+                const float* z = zt + rr * zld;
+                const int k0 = 8 * lane;
+                float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = k0 < KP ? z[k0 + e] : 0.f;
-            if (pt.G && k0 < KP) {
-                float4* g = reinterpret_cast<float4*>(pt.G + row * KP + k0);
-                g[0] = make_float4(v[0], v[1], v[2], v[3]);
-                g[1] = make_float4(v[4], v[5], v[6], v[7]);
+                for (int e = 0; e < 8; ++e) {
+                    const int k = k0 + e;
+                    float t = k < KP ? z[k] : 0.f;
+                    if (k == K) t = side == HYPMI_SIDE_ENROL ? t : 1.f;
+                    if (k == K + 1) t = side == HYPMI_SIDE_ENROL ? 1.f : z[KP];
+                    v[e] = t;
+                }
+                if (G && k0 < KP) {
+                    float4* g = reinterpret_cast<float4*>(G + row * KP + k0);
+                    g[0] = make_float4(v[0], v[1], v[2], v[3]);
+                    g[1] = make_float4(v[4], v[5], v[6], v[7]);
+                }
+                float m = pair_chunk_max(v);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+                const int up = pair_scale_exponent(m);
+                uint4* out = H + row * row_slots;
+                if (k0 < 16 * pt.ks16) pair_chunk_store(v, up, lane, hs, out);
+                if (lane == 0) pair_row_tail(up, pt.ks16, hs, row_slots, out);
             }
-            float m = pair_chunk_max(v);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-            const int up = pair_scale_exponent(m);
-            uint4* out = pt.H + row * row_slots;
-            if (k0 < 16 * pt.ks16) pair_chunk_store(v, up, lane, hs, out);
-            if (lane == 0) pair_row_tail(up, pt.ks16, hs, row_slots, out);
-        }
+        };
+        emit(pt.side, pt.H, pt.G);
+        if (pt.H_other) emit(pt.side == HYPMI_SIDE_ENROL ? HYPMI_SIDE_TEST : HYPMI_SIDE_ENROL, pt.H_other, nullptr);
     }
 }
 
@@ -536,7 +544,7 @@ int run_fused_tail(const hypmi_plan* p, const float* in, int64_t ldin, int64_t r
 
 // The fused tail with the packing and the fp16-pair conversion in its epilogue (shared-basis plans).
 int run_fused_tail_pairs(const hypmi_plan* p, const float* in, int64_t ldin, int64_t rows, int side, void* H,
-                         float* G, hipStream_t stream) {
+                         void* H_other, float* G, hipStream_t stream) {
     const FusedTail& f = p->fused;
     PairTail pt;
     pt.col_map = p->col_map;
@@ -546,6 +554,7 @@ int run_fused_tail_pairs(const hypmi_plan* p, const float* in, int64_t ldin, int
     pt.ks16 = 2 * ((p->KP + 31) / 32);
     pt.c = p->c;
     pt.H = static_cast<uint4*>(H);
+    pt.H_other = static_cast<uint4*>(H_other);
     pt.G = G;
     const int lds1 = 64 * (p->KP + 1) * (int)sizeof(float), lds2 = 2 * lds1;
     const bool big = rows >= 128 * 2048 && lds2 <= 96 * 1024;
@@ -766,13 +775,13 @@ extern "C" int hypmi_prologue_pairs_supported(const hypmi_plan* p) {
 }
 
 extern "C" int hypmi_prologue_pairs(const hypmi_plan* p, const float* x, int64_t n, int64_t ldx, int side,
-                                    void* H, float* G, void* ws, int64_t ws_bytes, void* stream_) {
+                                    void* H, void* H_other, float* G, void* ws, int64_t ws_bytes, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     HYPMI_REQUIRE(hypmi_prologue_pairs_supported(p),
                   "prologue_pairs: this plan has no fused shared-basis tail; use hypmi_prologue + hypmi_pair_rows");
     HYPMI_REQUIRE(x && H, "prologue_pairs: null pointer");
     HYPMI_REQUIRE(n >= 0 && ldx >= round_up(p->d_in, 4) && ldx % 4 == 0 && aligned16(x) && aligned16(H) &&
-                      (!G || aligned16(G)),
+                      (!G || aligned16(G)) && (!H_other || aligned16(H_other)),
                   "prologue_pairs: buffers must be 16-byte aligned with ldx %% 4 == 0 and ldx >= d_in rounded up to 4");
     HYPMI_REQUIRE(side == HYPMI_SIDE_ENROL || side == HYPMI_SIDE_TEST, "prologue_pairs: bad side %d", side);
     if (n == 0) return HYPMI_OK;
@@ -792,6 +801,7 @@ extern "C" int hypmi_prologue_pairs(const hypmi_plan* p, const float* x, int64_t
         rc = run_segments(p, p->n_seg - 1, x + r0 * ldx, ldx, rows, w, nullptr, 0, &cur, &ldcur, stream);
         if (rc != HYPMI_OK) return rc;
         rc = run_fused_tail_pairs(p, cur, ldcur, rows, side, static_cast<char*>(H) + r0 * row_bytes,
+                                  H_other ? static_cast<char*>(H_other) + r0 * row_bytes : nullptr,
                                   G ? G + r0 * p->KP : nullptr, stream);
         if (rc != HYPMI_OK) return rc;
     }

@@ -323,7 +323,7 @@ class Plan:
             H = torch.empty(self._lib.hypmi_pair_bytes(self.kp, n) // 4, dtype=torch.int32, device=x.device)
             G = torch.empty((n, self.kp), dtype=torch.float32, device=x.device) if keep_rows else None
             ws, nbytes = self._workspace(n)
-            _lib.check(self._lib.hypmi_prologue_pairs(self._h, _ptr(x), n, x.stride(0), int(side), _ptr(H),
+            _lib.check(self._lib.hypmi_prologue_pairs(self._h, _ptr(x), n, x.stride(0), int(side), _ptr(H), None,
                                                       _ptr(G) if keep_rows else None, _ptr(ws), nbytes,
                                                       stream_ptr()))
             split = SplitRows(H, n, self.kp, fmt)
@@ -333,6 +333,24 @@ class Plan:
         if split is None:  # no 16-bit kernel for this width: the fp32 rows are the operand
             return (G, G) if keep_rows else G
         return (split, G) if keep_rows else split
+
+    def prologue_split_both(self, x, fmt=None):
+        """x -> (enrol-side, test-side) score operands of the same vectors (adaptive S-norm uses a test
+        vector as a row of the cohort panel and as a column of the trial matrix).  One pass over the
+        chain where the plan's prologue kernel writes fp16 pairs itself, two otherwise."""
+        torch = _torch()
+        fmt = fmt or DEFAULT_SPLIT
+        self._check_x(x)
+        n = x.shape[0]
+        if fmt == "pair" and n and self._lib.hypmi_prologue_pairs_supported(self._h):
+            nb = self._lib.hypmi_pair_bytes(self.kp, n) // 4
+            He = torch.empty(nb, dtype=torch.int32, device=x.device)
+            Ht = torch.empty(nb, dtype=torch.int32, device=x.device)
+            ws, nbytes = self._workspace(n)
+            _lib.check(self._lib.hypmi_prologue_pairs(self._h, _ptr(x), n, x.stride(0), SIDE_ENROL, _ptr(He),
+                                                      _ptr(Ht), None, _ptr(ws), nbytes, stream_ptr()))
+            return SplitRows(He, n, self.kp, fmt), SplitRows(Ht, n, self.kp, fmt)
+        return self.prologue_split(x, SIDE_ENROL, fmt), self.prologue_split(x, SIDE_TEST, fmt)
 
     def prologue_f64(self, x64, side):
         """x64: device float64 [n, d_in] -> (G64 [n, K + 2] rows [g, q(+c), |g|], bnd [n, 2] floats)."""

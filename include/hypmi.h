@@ -113,11 +113,14 @@ int hypmi_prologue(const hypmi_plan* plan, const float* x, int64_t n, int64_t ld
  * length-normalised step is fused with a shared-basis projection (hypmi_prologue_pairs_supported):
  * the per-column maps, q, the packed row and its conversion to scaled fp16 pairs happen on the
  * workgroup's LDS copy of the projected rows, which never reach memory.  Same reference lines as
- * hypmi_prologue.  H: hypmi_pair_bytes(kp, n) bytes; G (optional, [n x kp]) also receives the packed
- * fp32 rows, bit-identical to hypmi_prologue's; workspace as for hypmi_prologue. */
+ * hypmi_prologue.  H: hypmi_pair_bytes(kp, n) bytes; H_other (optional, same size) receives the same
+ * vectors packed for the OTHER side of a trial (adaptive S-norm scores every test vector both as a
+ * row of the cohort panel and as a column of the trial matrix: one pass over the chain instead of
+ * two); G (optional, [n x kp]) also receives the packed fp32 rows of `side`, bit-identical to
+ * hypmi_prologue's; workspace as for hypmi_prologue. */
 int hypmi_prologue_pairs_supported(const hypmi_plan* plan);
 int hypmi_prologue_pairs(const hypmi_plan* plan, const float* x, int64_t n, int64_t ldx, int side, void* H,
-                         float* G, void* workspace, int64_t workspace_bytes, void* stream);
+                         void* H_other, float* G, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* hypmi_prologue for callers that cannot allocate device memory or pass a workspace (code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc): the intermediate rows live

@@ -815,3 +815,7 @@ def test_prologue_pairs_equals_prologue_then_pair_rows(d, lda, K, n):
         assert torch.equal(G2, G)
         got_only = plan.prologue_split(x, side)
         assert torch.equal(got_only.H[:nb], want.H[:nb])
+    both = plan.prologue_split_both(x)  # one pass, both packings
+    for side, got in zip((SIDE_ENROL, SIDE_TEST), both):
+        want = engine.split_rows(plan.prologue(x, side), "pair")
+        assert torch.equal(got.H[:nb], want.H[:nb])
