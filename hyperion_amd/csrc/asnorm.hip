@@ -653,6 +653,56 @@ __global__ __launch_bounds__(TR_THREADS) void topk_rows_reg_kernel(const float* 
     unsigned selbits[SELW], basev[NW];
 #pragma unroll
     for (int w = 0; w < SELW; ++w) selbits[w] = above_hi[w] & ~above_lo[w] & valid[w];
+    const int groups = (k + 7) >> 3;
+
+    if (k <= TR_ORDER) {
+        // bank_order: the list leaves ordered by (index mod 32) -- the class of LDS banks a member's
+        // values fall into in the gather -- and rotated by a (row mod 32)-th of its length, so that the
+        // 32 lists a half wave walks in step are in different classes most of the time.  Member
+        // j * 256 + tid is in class tid & 31: all members of a thread share one class, so a thread's
+        // members go to consecutive places behind those of the threads of its class with a lower
+        // number, and the order inside a list is (class, thread, item): the same for the same input.
+        unsigned mine = 0;
+#pragma unroll
+        for (int w = 0; w < SELW; ++w) mine += __builtin_popcount(selbits[w]);
+        const int b = tid & 31, part = tid >> 5;
+        bank_cnt[part][b] = (unsigned short)mine;
+        __syncthreads();
+        if (tid < 32) {  // first place of every class: exclusive scan of the class totals
+            int tot = 0;
+#pragma unroll
+            for (int q2 = 0; q2 < 8; ++q2) tot += bank_cnt[q2][tid];
+            int incl = tot;
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                const int v = __shfl_up(incl, off, 64);
+                if (tid >= off) incl += v;
+            }
+            bank_start[tid] = (unsigned short)(incl - tot);
+        }
+        if (tid < 8 && k + tid < 8 * groups) ordered[k + tid] = 0;  // tail of the last group
+        __syncthreads();
+        int at = bank_start[b];
+        for (int q2 = 0; q2 < part; ++q2) at += bank_cnt[q2][b];
+        at -= (int)(((row & 31) * k) >> 5);  // the rotation
+#pragma unroll
+        for (int w = 0; w < SELW; ++w) {
+            unsigned bits = selbits[w];
+            while (bits) {
+                const int j = 32 * w + __builtin_ctz(bits);
+                bits &= bits - 1;
+                const int dst = at < 0 ? at + k : at;
+                if (dst < k) ordered[dst] = (unsigned short)(j * TR_THREADS + tid);  // (always: exactly k are selected)
+                ++at;
+            }
+        }
+        __syncthreads();
+        for (int g = tid; g < groups; g += TR_THREADS)
+            reinterpret_cast<uint4*>(idx8)[(int64_t)g * ldi + row] = reinterpret_cast<const uint4*>(ordered)[g];
+        return;
+    }
+
+    // Longer lists leave in ascending index order.
     ordered_bases(selbits, basev);
 #pragma unroll
     for (int w = 0; w < SELW; ++w) opaque(selbits[w]);  // recompute the ballots rather than keep ITEMS masks
@@ -660,7 +710,6 @@ __global__ __launch_bounds__(TR_THREADS) void topk_rows_reg_kernel(const float* 
     // The list goes through LDS so that it leaves as 16-byte groups (one store per eight entries)
     // instead of k scattered 2-byte stores; lists longer than the staging buffer are written directly.
     const bool staged = k <= TR_STAGE;
-    const int groups = (k + 7) >> 3;
     if (tid < 8) {
         if (staged) stage[8 * (groups - 1) + tid] = 0;  // tail of the last group
         else if (k + tid < 8 * groups) idx8[((int64_t)(groups - 1) * ldi + row) * 8 + ((k + tid) & 7)] = 0;
@@ -678,49 +727,8 @@ __global__ __launch_bounds__(TR_THREADS) void topk_rows_reg_kernel(const float* 
     }
     if (staged) {
         __syncthreads();
-        const unsigned short* src_list = stage;
-        if (k <= TR_ORDER) {
-            // bank_order: members by (index mod 32), the class of LDS banks their values fall into in
-            // the gather, then rotated by a (row mod 32)-th of the list, so that the 32 lists a half
-            // wave walks in step are in different classes most of the time.  Stable within a class:
-            // thread (part, b) takes the members of class b in the part-th eighth of the staged list.
-            const int b = tid & 31, part = tid >> 5, per = (k + 7) >> 3;
-            const int p0 = part * per, p1 = p0 + per < k ? p0 + per : k;
-            int mine = 0;
-            for (int p = p0; p < p1; ++p) mine += (stage[p] & 31) == b ? 1 : 0;
-            bank_cnt[part][b] = (unsigned short)mine;
-            __syncthreads();
-            if (tid < 32) {  // first member of every class: exclusive scan of the class totals
-                int tot = 0;
-#pragma unroll
-                for (int q2 = 0; q2 < 8; ++q2) tot += bank_cnt[q2][tid];
-                int incl = tot;
-#pragma unroll
-                for (int off = 1; off < 32; off <<= 1) {
-                    const int v = __shfl_up(incl, off, 64);
-                    if (tid >= off) incl += v;
-                }
-                bank_start[tid] = (unsigned short)(incl - tot);
-            }
-            __syncthreads();
-            int at = bank_start[b];
-            for (int q2 = 0; q2 < part; ++q2) at += bank_cnt[q2][b];
-            const int rot = (int)(((row & 31) * k) >> 5);
-            for (int p = p0; p < p1; ++p) {
-                const unsigned short c = stage[p];
-                if ((c & 31) == b) {
-                    int dst = at - rot;
-                    if (dst < 0) dst += k;
-                    ordered[dst] = c;
-                    ++at;
-                }
-            }
-            if (tid < 8 && k + tid < 8 * groups) ordered[k + tid] = 0;  // tail of the last group
-            __syncthreads();
-            src_list = ordered;
-        }
         for (int g = tid; g < groups; g += TR_THREADS)
-            reinterpret_cast<uint4*>(idx8)[(int64_t)g * ldi + row] = reinterpret_cast<const uint4*>(src_list)[g];
+            reinterpret_cast<uint4*>(idx8)[(int64_t)g * ldi + row] = reinterpret_cast<const uint4*>(stage)[g];
     }
 }
 

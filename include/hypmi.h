@@ -242,7 +242,8 @@ int hypmi_scatter_block(const float* blk, int64_t ldb, const int32_t* ri, int64_
  * (adapt_s_norm.py:42-44, 65-67); ties at a boundary are resolved towards the lower cohort index
  * (numpy leaves that order unspecified).  The ORDER of the members inside a list is not their rank
  * (the statistics taken over a list do not depend on it): lists of up to 2048 members leave ordered
- * by (index mod 32) and rotated by (row mod 32), which spreads the lanes of a half wave of
+ * by (index mod 32), then (index mod 256), then index, and rotated by (row mod 32) / 32 of their
+ * length, which spreads the lanes of a half wave of
  * hypmi_gather_stats over the LDS banks; longer ones leave in ascending index order.  The same
  * input always gives the same list.
  * List layout (uint16, groups of eight so that one 16-byte load fetches eight entries of a list):

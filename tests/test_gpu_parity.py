@@ -686,9 +686,9 @@ def test_topk_rows_matches_stable_argsort(n, nc, k, disc, shift):
 
 @pytest.mark.gpu
 def test_topk_lists_are_ordered_by_bank_class():
-    """Lists of up to 2048 members leave the top-k kernel ordered by (index mod 32), ascending index
-    inside a class, rotated by (row mod 32) / 32 of the list; the same call twice gives the same
-    lists."""
+    """Lists of up to 2048 members leave the top-k kernel ordered by (index mod 32), inside a class by
+    (index mod 256, index) -- the thread that held the member, then its item --, rotated by
+    (row mod 32) / 32 of the list; the same call twice gives the same lists."""
     import torch
 
     from hyperion_amd.score_norm.adapt_s_norm import lists_to_numpy, topk_rows
@@ -700,7 +700,7 @@ def test_topk_lists_are_ordered_by_bank_class():
     assert np.array_equal(idx, lists_to_numpy(topk_rows(A, k, 0), k))
     for r in range(n):
         members = np.sort(idx[r])
-        by_class = members[np.argsort(members % 32, kind="stable")]
+        by_class = members[np.lexsort((members, members % 256, members % 32))]
         assert np.array_equal(idx[r], np.roll(by_class, -((r % 32) * k // 32))), r
 
 
