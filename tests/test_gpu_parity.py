@@ -819,3 +819,73 @@ def test_prologue_pairs_equals_prologue_then_pair_rows(d, lda, K, n):
     for side, got in zip((SIDE_ENROL, SIDE_TEST), both):
         want = engine.split_rows(plan.prologue(x, side), "pair")
         assert torch.equal(got.H[:nb], want.H[:nb])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,nc,k,lists", [
+    (5, 30_000, 300, 70),      # one row per workgroup (the row alone nearly fills LDS)
+    (3, 20_440, 17, 1025),     # two rows per workgroup, the largest cohort that allows it; odd row count
+    (2, 20_441, 8, 5),         # one member more: back to one row per workgroup
+    (7, 9_000, 1, 33),         # four rows per workgroup, lists of one member
+    (9, 4_000, 9, 2_050),      # a partial last group of one entry, more than two rounds of lists per lane
+    (4, 600, 600, 3),          # every member selected
+    (1, 64, 64, 1)])
+def test_gather_stats_shapes(rows, nc, k, lists):
+    """hypmi_gather_stats on every rows-per-workgroup variant of the LDS-resident kernel, ragged list
+    lengths and list counts, against float64 numpy on the same lists (the lists come from the top-k
+    kernel, so they are in its bank order)."""
+    import torch
+
+    from hyperion_amd.score_norm.adapt_s_norm import gather_stats, lists_to_numpy, topk_rows
+
+    rng = np.random.RandomState(rows * 1000 + k)
+    X = (rng.randn(rows, nc) * 4 - 9).astype(np.float32)
+    X[0, :] += 50.0 * (rng.rand(nc) < 0.01)  # a few far outliers in one row
+    sel_src = (rng.randn(lists, nc) * 3).astype(np.float32)
+    idx = topk_rows(torch.from_numpy(sel_src).cuda(), k, 0)
+    L = lists_to_numpy(idx, k)
+    mean, istd, _ = gather_stats(torch.from_numpy(X).cuda(), None, idx, lists, 1e-5, k)
+    mean, istd = mean[:, :lists].cpu().numpy().astype(np.float64), istd[:, :lists].cpu().numpy().astype(np.float64)
+    sel = X.astype(np.float64)[:, L]  # [rows, lists, k]
+    m_ref = sel.mean(axis=2)
+    s_ref = np.maximum(sel.std(axis=2), 1e-5)
+    assert np.max(np.abs(mean - m_ref) / np.maximum(np.abs(m_ref), 1.0)) <= 2e-6
+    assert np.max(np.abs(istd * s_ref - 1.0)) <= (2e-5 if k > 1 else 1e-6)
+
+
+@pytest.mark.gpu
+def test_gather_stats_tail_selection_and_constant_members():
+    """Selections far out in the tail of their row (where a one-pass variance about the row's pivot
+    would cancel) and selections of equal values: the kernel redoes those pairs around the list's own
+    pivot; the count of such pairs is reported."""
+    import ctypes
+
+    import torch
+
+    from hyperion_amd import _lib
+    from hyperion_amd.score_norm.adapt_s_norm import gather_stats, lists_to_numpy, topk_rows
+
+    rng = np.random.RandomState(4)
+    rows, nc, k, lists = 6, 20_000, 300, 40
+    X = (rng.randn(rows, nc) * 6 - 14).astype(np.float32)
+    X[2, :400] = 7.25          # a block of equal values
+    X[3, :400] = 60.0 + 0.01 * rng.randn(400).astype(np.float32)  # a narrow cluster 12 sigma away
+    sel_src = (rng.randn(lists, nc)).astype(np.float32)
+    sel_src[:20, :400] += 100.0  # the first 20 lists select inside the first 400 members
+    idx = topk_rows(torch.from_numpy(sel_src).cuda(), k, 0)
+    L = lists_to_numpy(idx, k)
+    lib = _lib.load()
+    n0 = ctypes.c_ulonglong(0)
+    _lib.check(lib.hypmi_gather_redo_count(ctypes.byref(n0), 1))
+    mean, istd, _ = gather_stats(torch.from_numpy(X).cuda(), None, idx, lists, 1e-5, k)
+    n1 = ctypes.c_ulonglong(0)
+    _lib.check(lib.hypmi_gather_redo_count(ctypes.byref(n1), 0))
+    assert n1.value >= 20  # at least the lists inside the blocks of rows 2 and 3 (pairs of rows share a redo)
+    mean, istd = mean[:, :lists].cpu().numpy().astype(np.float64), istd[:, :lists].cpu().numpy().astype(np.float64)
+    sel = X.astype(np.float64)[:, L]
+    m_ref, s_ref = sel.mean(axis=2), np.maximum(sel.std(axis=2), 1e-5)
+    assert np.all(istd[2, :20] == np.float32(1e5))  # exactly zero variance -> the floor
+    assert np.max(np.abs(mean - m_ref) / np.maximum(np.abs(m_ref), 1.0)) <= 2e-6
+    ok = np.ones_like(s_ref, bool)
+    ok[2, :20] = False
+    assert np.max(np.abs(istd * s_ref - 1.0)[ok]) <= 2e-5
