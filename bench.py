@@ -383,7 +383,7 @@ def score_matrix_stage(plda, preproc, n=100_000, reps=3):
                      "algorithmic_fp32_TFLOPs": tf, "pct_fp32_mfma_peak": 100.0 * tf / FP32_MFMA_PEAK_TFLOPS,
                      "hbm_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
     res["fp16_pair"]["note"] = ("products on the fp16 matrix cores (3 partial products per fp32 product), so the "
-                                "fp32 matrix peak is not this kernel's roof: HBM stores are")
+                                "fp32 matrix peak is not this kernel's roof: the HBM store of the score matrix is (hbm_frac)")
     return res
 
 
