@@ -40,9 +40,9 @@ WORKLOADS = {
     # one GPU's share of the 1M x 1M matrix on 8 GPUs (125 000 tests per GPU: `--gpus 8` is the whole
     # job); the normalised scores are never kept, every block goes into target / non-target histograms
     "asnorm_1m_125k": dict(n_enrol=1_000_000, n_test=125_000, d=512, lda=200, K=150, n_coh=20_000, nbest=300,
-                           sink=True, test_chunk=4096),
+                           sink=True, test_chunk=32768),
     "asnorm_100k_16k": dict(n_enrol=100_000, n_test=16_384, d=512, lda=200, K=150, n_coh=20_000, nbest=300,
-                            sink=True, test_chunk=4096),
+                            sink=True, test_chunk=32768),
     "asnorm_tiny": dict(n_enrol=300, n_test=2_000, d=512, lda=200, K=150, n_coh=1_000, nbest=100),
     # raw scores only (no normalisation): chain + SPLDA, full score matrix
     "chain_splda_100k": dict(n_enrol=100_000, n_test=100_000, d=512, lda=200, K=150),
@@ -387,6 +387,23 @@ def score_matrix_stage(plda, preproc, n=100_000, reps=3):
     return res
 
 
+def million_share_stage(plda, preproc):
+    """The `asnorm_1m_125k` workload for one timed step: all 1 000 000 enrolment models against the
+    125 000 tests one GPU of an 8-GPU node owns, every block of normalised scores streamed into the
+    target / non-target histograms (1.25e11 trials, none kept)."""
+    import torch
+
+    cfg = WORKLOADS["asnorm_1m_125k"]
+    dt, st, be, bufs = asnorm_run(plda, preproc, cfg, 1, 0, 0, 1, None)
+    res = {"workload": "asnorm_1m_125k", "steps": 1, "warmup": 0, "s_per_step": dt,
+           "scores_per_s": cfg["n_enrol"] * float(cfg["n_test"]) / dt,
+           "stages_ms_per_step": st["per_step_ms"], "trials_counted": st["sink"]["trials"],
+           "eer": st["sink"]["eer"]}
+    del be, bufs
+    torch.cuda.empty_cache()
+    return res
+
+
 def main_asnorm(args, cfg, chain, model, plda, preproc, world, rank, dist):
     """AS-norm workloads: value = normalised scores/s over all ranks (test rows sharded)."""
     import torch
@@ -454,6 +471,10 @@ def main_asnorm(args, cfg, chain, model, plda, preproc, world, rank, dist):
             out["score_matrix_stage"] = score_matrix_stage(plda, preproc)
         except Exception as e:  # noqa: BLE001
             out["score_matrix_stage"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:  # one GPU's share of the 1M x 1M configuration, one step (kernels are warm from the run above)
+            out["share_of_1m_x_1m_stage"] = million_share_stage(plda, preproc)
+        except Exception as e:  # noqa: BLE001
+            out["share_of_1m_x_1m_stage"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and chain is not None:
         try:
             out["cpu_baseline"] = cpu_baseline_asnorm(cfg, chain, model)

@@ -61,6 +61,11 @@ def all_gather_lists(local, counts, group=None):
     return torch.cat([recv[r, :, :counts[r]] for r in range(world)], dim=1).contiguous()
 
 
+def _rows(G, r0, r1):
+    """Rows r0..r1-1 of packed rows in either form (fp32 matrix or SplitRows)."""
+    return G.rows(r0, r1) if isinstance(G, engine.SplitRows) else G[r0:r1]
+
+
 class PLDABackend:
     """plda: a hyperion_amd SPLDA / FRPLDA / PLDA; preproc: optional TransformList folded into the
     embedding prologue; nbest / nbest_discard: adaptive S-norm cohort selection."""
@@ -71,6 +76,11 @@ class PLDABackend:
         self.nbest = int(nbest)
         self.nbest_discard = int(nbest_discard)
         self.test_chunk = int(test_chunk)
+        # bound on the six [enrol, chunk] fp32 intermediates of one tile (two pairs of cohort statistics,
+        # raw and normalised scores): with more enrolment models than this allows per chunk of tests the
+        # enrolment rows are walked in blocks, so that the chunk of tests can stay long (every workgroup of
+        # the statistics kernels amortises its rows over the lists of one tile)
+        self.tile_bytes = 96 << 30
         # re-decide top-k members that fp32 cannot separate from the selection boundary with fp64
         # scores (costs one fp64 prologue per vector; without it ~0.05 % of test columns pick one
         # different cohort member than float64 arithmetic would)
@@ -161,7 +171,8 @@ class PLDABackend:
         """AS-normalised scores of every enrolment model against `x_test` (this rank's shard).
         cohort: result of prepare_cohort.  Returns a device [n_enrol, n_test] tensor, or, when
         `reduce` is given, calls reduce(col0, block) on every [n_enrol, chunk] block instead of
-        keeping the matrix (for trial sets whose score matrix does not fit)."""
+        keeping the matrix (for trial sets whose score matrix does not fit); when the enrolment rows
+        are walked in blocks (see tile_bytes) the call is reduce(col0, block, row0)."""
         from . import _lib
 
         torch = engine.require_gpu()
@@ -173,6 +184,10 @@ class PLDABackend:
         if out is None and reduce is None:
             ld = engine.round_up(max(nt, 1), 32)
             out = torch.empty((ne, ld), dtype=torch.float32, device=xt.device)[:, :nt]
+        chunk = max(1, min(self.test_chunk, nt))
+        eb = ne  # enrolment rows per tile
+        if 24 * ne * chunk > self.tile_bytes:
+            eb = max(1024, self.tile_bytes // (24 * chunk) // 1024 * 1024)
         for c0 in range(0, nt, self.test_chunk):
             c1 = min(nt, c0 + self.test_chunk)
             xc = xt[c0:c1]
@@ -187,21 +202,28 @@ class PLDABackend:
                     return dict(cohort["coh64"], G_rows=Gt64, bnd_rows=bt)
                 exact = T("prologue_f64", f64_rows)
             t_idx = T("topk_test", lambda: topk_rows(A_tc, k, self.nbest_discard, exact))  # [k, chunk]
-            mz, iz, ldz = T("gather_z", lambda: gather_stats(A_ec, None, t_idx, c1 - c0, 1e-5, k),
-                            (ne, c1 - c0, k))                                             # [enrol, chunk]
-            mt, it, ldt = T("gather_t", lambda: gather_stats(A_tc, None, e_idx, ne, 1e-5, k),
-                            (c1 - c0, ne, k))                                             # [chunk, enrol]
-            S = T("score_trials", lambda: engine.score(Ge, Gt_cols))                      # [enrol, chunk]
-            if reduce is None:
-                dst = out[:, c0:c1]
-            else:
-                dst = torch.empty((ne, engine.round_up(c1 - c0, 32)), dtype=torch.float32,
-                                  device=xt.device)[:, :c1 - c0]
-            T("apply", lambda: _lib.check(lib.hypmi_asnorm_apply(
-                engine._ptr(S), S.stride(0), ne, c1 - c0, engine._ptr(mz), engine._ptr(iz), ldz, engine._ptr(mt),
-                engine._ptr(it), ldt, engine._ptr(dst), dst.stride(0), engine.stream_ptr())))
-            if reduce is not None:
-                reduce(c0, dst)
+            nq = c1 - c0
+            for e0 in range(0, ne, eb):
+                e1 = min(ne, e0 + eb)
+                mz, iz, ldz = T("gather_z", lambda: gather_stats(A_ec[e0:e1], None, t_idx, nq, 1e-5, k),
+                                (e1 - e0, nq, k))                                         # [enrol, chunk]
+                mt, it, ldt = T("gather_t", lambda: gather_stats(A_tc, None, e_idx[:, e0:e1], e1 - e0, 1e-5, k),
+                                (nq, e1 - e0, k))                                         # [chunk, enrol]
+                S = T("score_trials", lambda: engine.score(_rows(Ge, e0, e1), Gt_cols))     # [enrol, chunk]
+                if reduce is None:
+                    dst = out[e0:e1, c0:c1]
+                else:
+                    dst = torch.empty((e1 - e0, engine.round_up(nq, 32)), dtype=torch.float32,
+                                      device=xt.device)[:, :nq]
+                T("apply", lambda: _lib.check(lib.hypmi_asnorm_apply(
+                    engine._ptr(S), S.stride(0), e1 - e0, nq, engine._ptr(mz), engine._ptr(iz), ldz,
+                    engine._ptr(mt), engine._ptr(it), ldt, engine._ptr(dst), dst.stride(0), engine.stream_ptr())))
+                if reduce is not None:
+                    if eb >= ne:
+                        reduce(c0, dst)
+                    else:
+                        reduce(c0, dst, e0)
+                del mz, iz, mt, it, S, dst
         if self.exact_topk:
             self._warn_skipped()  # one read of two counters per call
         return out

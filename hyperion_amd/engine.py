@@ -405,6 +405,15 @@ class SplitRows:
     def device(self):
         return self.H.device
 
+    def rows(self, r0, r1):
+        """Rows r0..r1-1 as SplitRows on the same storage (rows are stored one after the other; the
+        kernels may read up to 1 KiB past the last row of a tile, which stays inside the parent)."""
+        assert 0 <= r0 <= r1 <= self.n
+        if r0 == 0 and r1 == self.n:
+            return self
+        row_i32 = getattr(_lib.load(), SPLIT_FORMATS[self.fmt][0])(self.kp) // 4
+        return SplitRows(self.H[r0 * row_i32:], r1 - r0, self.kp, self.fmt)
+
 
 def split_rows(G, fmt=None):
     """Packed fp32 rows [n, kp] -> SplitRows, or None when kp has no split kernel."""

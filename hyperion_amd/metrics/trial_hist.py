@@ -319,14 +319,16 @@ class TrialHistogram:
         return self
 
     def sink(self, key_enrol, key_test):
-        """A `reduce` callback for PLDABackend.score_snorm: block [n_enrol, chunk] of the tests
-        starting at column c0."""
+        """A `reduce` callback for PLDABackend.score_snorm: block [rows, chunk] of the enrolment rows
+        starting at r0 against the tests starting at column c0."""
         torch = engine.require_gpu()
         kt_all = key_test if isinstance(key_test, torch.Tensor) else torch.from_numpy(
             np.ascontiguousarray(key_test, dtype=np.int32)).cuda()
+        ke_all = key_enrol if isinstance(key_enrol, torch.Tensor) else torch.from_numpy(
+            np.ascontiguousarray(key_enrol, dtype=np.int32)).cuda()
 
-        def reduce(c0, block):
-            self.add(block, key_enrol, kt_all[c0:c0 + block.shape[1]])
+        def reduce(c0, block, r0=0):
+            self.add(block, ke_all[r0:r0 + block.shape[0]], kt_all[c0:c0 + block.shape[1]])
 
         return reduce
 

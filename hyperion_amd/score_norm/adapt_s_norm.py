@@ -59,17 +59,19 @@ def lists_to_numpy(idx, k):
 
 
 def gather_stats(X, mask_u8, idx, n_lists, std_floor, k):
-    """mean / inverse std of X[r, list_q] for every row r and list q: two device [rows, lists]."""
+    """mean / inverse std of X[r, list_q] for every row r and list q: two device [rows, lists].
+    idx: grouped lists as topk_rows makes them, or a range of their lists (`idx[:, q0:q1]`)."""
     torch = engine.require_gpu()
     lib = _lib.load()
     n, nc = X.shape
+    assert idx.stride(2) == 1 and idx.stride(1) == 8 and idx.shape[1] >= n_lists
     ld = engine.round_up(max(n_lists, 1), 4)
     mean = torch.empty((n, ld), dtype=torch.float32, device=X.device)
     istd = torch.empty((n, ld), dtype=torch.float32, device=X.device)
     _lib.check(lib.hypmi_gather_stats(engine._ptr(X), n, nc, X.stride(0),
                                       engine._ptr(mask_u8) if mask_u8 is not None else None,
                                       mask_u8.stride(0) if mask_u8 is not None else 0,
-                                      engine._ptr(idx), idx.shape[1], int(k), n_lists,
+                                      engine._ptr(idx), idx.stride(0) // 8, int(k), n_lists,
                                       float(std_floor), engine._ptr(mean), engine._ptr(istd), ld,
                                       engine.stream_ptr()))
     return mean, istd, ld

@@ -374,6 +374,43 @@ def test_backend_snorm_pipeline_chunked_and_sharded():
     assert abs(sum(v for _, v in acc) - got.sum()) <= 1e-3 * abs(got).sum()
 
 
+@pytest.mark.gpu
+def test_backend_snorm_enrol_rows_walked_in_blocks():
+    """With more enrolment rows than the tile budget allows per chunk of tests, the rows are walked in
+    blocks (row ranges of the packed rows, of the enrol-vs-cohort panel and of the per-enrolment
+    lists): same result as one tile, for the matrix and for the streamed blocks."""
+    import torch
+
+    import synth
+    from hyperion_amd.backend import PLDABackend
+    from hyperion_amd.metrics import TrialHistogram
+    from hyperion_amd.pdfs.plda import SPLDA
+
+    m = synth.make_splda(40, 12)
+    xe, ce = synth.raw_xvectors(2500, d=40, seed=21, num_centers=30)
+    xt, ct = synth.raw_xvectors(700, d=40, seed=22, num_centers=30)
+    xc, _ = synth.raw_xvectors(400, d=40, seed=23, num_centers=200)
+    be = PLDABackend(SPLDA(mu=m["mu"], V=m["V"], W=m["W"]), None, nbest=50, test_chunk=512)
+    coh = be.prepare_cohort(xe, xc)
+    whole = be.score_snorm(xt, coh).cpu().numpy()
+    be.tile_bytes = 24 * 512 * 1024  # 1024 enrolment rows per tile: blocks of 1024, 1024 and 452
+    tiled = be.score_snorm(xt, coh).cpu().numpy()
+    assert np.array_equal(tiled, whole)
+    seen = []
+    h = TrialHistogram(-60.0, 60.0, 512)
+    sink = h.sink(ce, ct)
+
+    def reduce(c0, blk, r0):
+        seen.append((c0, r0, tuple(blk.shape)))
+        assert torch.equal(blk, torch.from_numpy(whole[r0:r0 + blk.shape[0], c0:c0 + blk.shape[1]]).cuda())
+        sink(c0, blk, r0)
+
+    assert be.score_snorm(xt, coh, reduce=reduce) is None
+    assert seen == [(c0, r0, (min(1024, 2500 - r0), min(512, 700 - c0))) for c0 in (0, 512) for r0 in (0, 1024, 2048)]
+    ref = TrialHistogram(-60.0, 60.0, 512).add(torch.from_numpy(whole).cuda(), ce, ct)
+    assert all(np.array_equal(a, b) for a, b in zip(h.counts(), ref.counts()))
+
+
 def test_strict_relative_parity_with_refinement():
     """With the fp64 refinement pass (default for numpy inputs) every score of the VoxCeleb-size
     matrix matches the float64 oracle to 1e-4 RELATIVE, including those that cancel to ~0; without
