@@ -15,7 +15,7 @@ import numpy as np
 
 from . import engine
 from .engine import SIDE_ENROL, SIDE_TEST
-from .score_norm.adapt_s_norm import gather_stats, topk_rows
+from .score_norm.adapt_s_norm import gather_apply, gather_apply_supported, gather_stats, topk_rows
 
 
 def shard_range(n, part, num_parts):
@@ -81,6 +81,8 @@ class PLDABackend:
         # enrolment rows are walked in blocks, so that the chunk of tests can stay long (every workgroup of
         # the statistics kernels amortises its rows over the lists of one tile)
         self.tile_bytes = 96 << 30
+        # finish the normalisation inside the Z-part statistics kernel (no separate apply pass)
+        self.fuse_apply = True
         # re-decide top-k members that fp32 cannot separate from the selection boundary with fp64
         # scores (costs one fp64 prologue per vector; without it ~0.05 % of test columns pick one
         # different cohort member than float64 arithmetic would)
@@ -184,6 +186,7 @@ class PLDABackend:
         if out is None and reduce is None:
             ld = engine.round_up(max(nt, 1), 32)
             out = torch.empty((ne, ld), dtype=torch.float32, device=xt.device)[:, :nt]
+        fused = self.fuse_apply and gather_apply_supported(A_ec.shape[1], ne)
         chunk = max(1, min(self.test_chunk, nt))
         eb = ne  # enrolment rows per tile
         if 24 * ne * chunk > self.tile_bytes:
@@ -205,25 +208,33 @@ class PLDABackend:
             nq = c1 - c0
             for e0 in range(0, ne, eb):
                 e1 = min(ne, e0 + eb)
-                mz, iz, ldz = T("gather_z", lambda: gather_stats(A_ec[e0:e1], None, t_idx, nq, 1e-5, k),
-                                (e1 - e0, nq, k))                                         # [enrol, chunk]
                 mt, it, ldt = T("gather_t", lambda: gather_stats(A_tc, None, e_idx[:, e0:e1], e1 - e0, 1e-5, k),
                                 (nq, e1 - e0, k))                                         # [chunk, enrol]
-                S = T("score_trials", lambda: engine.score(_rows(Ge, e0, e1), Gt_cols))     # [enrol, chunk]
+                S = T("score_trials", lambda: engine.score(_rows(Ge, e0, e1), Gt_cols))   # [enrol, chunk]
                 if reduce is None:
                     dst = out[e0:e1, c0:c1]
                 else:
                     dst = torch.empty((e1 - e0, engine.round_up(nq, 32)), dtype=torch.float32,
                                       device=xt.device)[:, :nq]
-                T("apply", lambda: _lib.check(lib.hypmi_asnorm_apply(
-                    engine._ptr(S), S.stride(0), e1 - e0, nq, engine._ptr(mz), engine._ptr(iz), ldz,
-                    engine._ptr(mt), engine._ptr(it), ldt, engine._ptr(dst), dst.stride(0), engine.stream_ptr())))
+                if fused:
+                    # Z-part statistics and the normalisation in one launch: the statistics never leave
+                    # the registers
+                    T("gather_z", lambda: gather_apply(A_ec[e0:e1], t_idx, nq, 1e-5, k, S, mt, it, ldt, dst),
+                      (e1 - e0, nq, k))
+                else:
+                    mz, iz, ldz = T("gather_z", lambda: gather_stats(A_ec[e0:e1], None, t_idx, nq, 1e-5, k),
+                                    (e1 - e0, nq, k))                                     # [enrol, chunk]
+                    T("apply", lambda: _lib.check(lib.hypmi_asnorm_apply(
+                        engine._ptr(S), S.stride(0), e1 - e0, nq, engine._ptr(mz), engine._ptr(iz), ldz,
+                        engine._ptr(mt), engine._ptr(it), ldt, engine._ptr(dst), dst.stride(0),
+                        engine.stream_ptr())))
+                    del mz, iz
                 if reduce is not None:
                     if eb >= ne:
                         reduce(c0, dst)
                     else:
                         reduce(c0, dst, e0)
-                del mz, iz, mt, it, S, dst
+                del mt, it, S, dst
         if self.exact_topk:
             self._warn_skipped()  # one read of two counters per call
         return out

@@ -908,6 +908,28 @@ __global__ __launch_bounds__(GS_THREADS) void gather_stats_kernel(
 // above does for every pair.
 constexpr int GP_RING = 4;
 constexpr float GP_AMP = 16.f;
+constexpr int GP_XCD_GROUPS = 16;  // row groups that share 128-byte lines of the transposed T-part statistics
+
+// The normalised score from the raw score and the two pairs of cohort statistics (mean, 1 / std):
+// one rounding per operation in this order wherever it is computed (no contraction into fma), so that
+// the fused and the separate paths give the same bits.
+__device__ __forceinline__ float asnorm_value(float s, float mz, float iz, float mt, float it) {
+    const float z = __fmul_rn(__fsub_rn(s, mz), iz);
+    const float t = __fmul_rn(__fsub_rn(s, mt), it);
+    return __fmul_rn(__fadd_rn(z, t), 0.70710678118654752440f);
+}
+
+// What the gather needs to finish the normalisation itself (rows = enrolment models, lists = tests):
+// raw scores S [rows, lists], T-part statistics mt / it [lists, rows] and the result [rows, lists].
+struct ApplyArgs {
+    const float* S;
+    int64_t lds;
+    const float* mt;
+    const float* it;
+    int64_t ldt;
+    float* out;
+    int64_t ldo;
+};
 constexpr int GP_SCRATCH_FLOATS = 80;  // per-wave partial sums of the pivot estimate (R x 16) + pad
 
 __device__ unsigned long long g_gather_redo;  // (row, list) pairs redone around a list pivot (diagnostic)
@@ -983,15 +1005,27 @@ __device__ __noinline__ ShiftedMoments<R> list_moments_shifted(const char* xb, c
     return m;
 }
 
-template <int R>
+// APPLY: instead of storing (mean, 1 / std) the kernel reads the raw score and the other side's
+// statistics of every (row, list) pair and stores the normalised score.  Those statistics are
+// transposed ([lists, rows]): a lane reads 4 R bytes of a 128-byte line that the workgroups of the
+// neighbouring rows need at about the same time, so the row groups are numbered such that
+// GP_XCD_GROUPS consecutive ones run on the same XCD (workgroups go to the XCDs round-robin) and
+// share those lines in its L2.  The loads ride in the shadow of the walk, which leaves HBM idle.
+template <int R, bool APPLY>
 __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
     const float* __restrict__ X, int64_t ldx, int64_t n_rows, int nc, const uint16_t* __restrict__ idx8,
     int64_t ldi, int k, int64_t Q, int64_t q_per_block, float floor_, float* __restrict__ mean,
-    float* __restrict__ istd, int64_t ldo) {
+    float* __restrict__ istd, int64_t ldo, ApplyArgs ap) {
     extern __shared__ __attribute__((aligned(16))) float xr[];
     float* red = xr + (size_t)nc * R;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t r0 = (int64_t)blockIdx.x * R;
+    int64_t grp = blockIdx.x;
+    if (APPLY) {  // the grid is padded to whole sets of 8 x GP_XCD_GROUPS row groups
+        const int64_t slot = grp >> 3, xcd = grp & 7;
+        grp = ((slot / GP_XCD_GROUPS) * 8 + xcd) * GP_XCD_GROUPS + slot % GP_XCD_GROUPS;
+        if (grp * R >= n_rows) return;
+    }
+    const int64_t r0 = grp * R;
     // pivot of a row: mean of its first min(nc, 1024) entries (the cohort order carries no meaning)
     float rowpiv[R];
     {
@@ -1064,6 +1098,24 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
             p_ld += ldi;                                             \
         }                                                            \
     }
+    // APPLY: what the end of a list needs from global memory -- the raw scores of the R rows and the R
+    // transposed statistics (one 4 R-byte load each) -- is requested when the list begins, so that the
+    // requests of the sixteen waves (which reach the ends of their lists together) have a whole list's
+    // walk to drain instead of stalling everyone at once.
+    typename LdsVec<R>::type pm, pi;
+    float ps[R];
+#define HYPMI_APPLY_PREFETCH(LIST)                                                                  \
+    if (APPLY) {                                                                                    \
+        int64_t qq = q0 + tid + (int64_t)(LIST) * GS_THREADS;                                       \
+        qq = qq < q1 ? qq : q1 - 1;                                                                 \
+        pm = *reinterpret_cast<const typename LdsVec<R>::type*>(ap.mt + qq * ap.ldt + r0);          \
+        pi = *reinterpret_cast<const typename LdsVec<R>::type*>(ap.it + qq * ap.ldt + r0);          \
+        _Pragma("unroll") for (int rr = 0; rr < R; ++rr) {                                          \
+            const int64_t e = r0 + rr < n_rows ? r0 + rr : n_rows - 1;                              \
+            ps[rr] = __builtin_nontemporal_load(ap.S + e * ap.lds + qq);                            \
+        }                                                                                           \
+    }
+    HYPMI_APPLY_PREFETCH(0)
 #pragma unroll
     for (int d = 0; d < GP_RING; ++d)
         if (d < n) HYPMI_NEXT_LOAD(ring[d])
@@ -1131,13 +1183,20 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
                         // 1 / max(sqrt(var), floor): v_rsq_f32 is good to one unit in the last place
                         const float is = var < floor2 ? inv_floor : __builtin_amdgcn_rsqf(var);
                         if (live_q && r0 + rr < n_rows) {
-                            mean[(r0 + rr) * ldo + q] = (rowpiv[rr] + lp[rr]) + md;
-                            istd[(r0 + rr) * ldo + q] = is;
+                            const float m = (rowpiv[rr] + lp[rr]) + md;
+                            if (APPLY) {
+                                ap.out[(r0 + rr) * ap.ldo + q] = asnorm_value(
+                                    ps[rr], m, is, lds_vec_elem<R>(pm, rr), lds_vec_elem<R>(pi, rr));
+                            } else {
+                                mean[(r0 + rr) * ldo + q] = m;
+                                istd[(r0 + rr) * ldo + q] = is;
+                            }
                         }
                         s1[rr] = s2[rr] = 0.f;
                     }
                     g = 0;
                     ++l;
+                    if (l < nl) HYPMI_APPLY_PREFETCH(l)
                 }
             }
         }
@@ -1145,6 +1204,7 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
 }
 
 #undef HYPMI_NEXT_LOAD
+#undef HYPMI_APPLY_PREFETCH
 
 // out[e, t] = ((S - mz[e,t]) * iz[e,t] + (S - mt[t,e]) * it[t,e]) / sqrt(2); the T-part statistics
 // arrive transposed and go through a 32 x 33 LDS tile.
@@ -1170,10 +1230,8 @@ __global__ __launch_bounds__(256) void asnorm_apply_kernel(const float* __restri
     for (int p = 0; p < 4; ++p) {
         const int64_t e = e0 + ty + 8 * p, t = t0 + tx;
         if (e < ne && t < nt) {
-            const float s = S[e * lds_ + t];
-            const float z = (s - mz[e * ldz + t]) * iz[e * ldz + t];
-            const float tn = (s - tm[tx][ty + 8 * p]) * ti[tx][ty + 8 * p];
-            out[e * ldo + t] = (z + tn) * 0.70710678118654752440f;
+            out[e * ldo + t] = asnorm_value(S[e * lds_ + t], mz[e * ldz + t], iz[e * ldz + t], tm[tx][ty + 8 * p],
+                                            ti[tx][ty + 8 * p]);
         }
     }
 }
@@ -1374,24 +1432,35 @@ inline int64_t pivot_lds_bytes(int nc, int R) {
     return round_up(((int64_t)nc * R + GP_SCRATCH_FLOATS) * 4, 16);
 }
 
-template <int R>
+template <int R, bool APPLY = false>
 int launch_gather_pivot(const float* X, int64_t n_rows, int nc, int64_t ldx, const uint16_t* idx8, int64_t ldi,
                         int k, int64_t n_lists, float std_floor, float* mean, float* istd, int64_t ldo,
-                        hipStream_t stream) {
+                        hipStream_t stream, const ApplyArgs& ap = ApplyArgs{}) {
     const int64_t lds_need = pivot_lds_bytes(nc, R);
     if (lds_need > 48 * 1024)
-        HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_pivot_kernel<R>),
+        HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_pivot_kernel<R, APPLY>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
     const int64_t groups = (n_rows + R - 1) / R;
-    HYPMI_REQUIRE(groups <= 0x7fffffffLL, "gather_stats: too many rows");
     int64_t chunks, q_per_block;
     gather_grid(groups, n_lists, &chunks, &q_per_block);
+    // with APPLY the row groups are renumbered in sets of 8 x GP_XCD_GROUPS: pad the grid to whole sets
+    const int64_t gx = APPLY ? round_up(groups, 8 * GP_XCD_GROUPS) : groups;
+    HYPMI_REQUIRE(gx <= 0x7fffffffLL, "gather_stats: too many rows");
     HYPMI_REQUIRE((q_per_block / GS_THREADS) * ((k + 7) / 8) < 0x7fffffffLL, "gather_stats: lists too long");
-    hipLaunchKernelGGL((gather_pivot_kernel<R>), dim3((unsigned)groups, (unsigned)chunks), dim3(GS_THREADS),
+    hipLaunchKernelGGL((gather_pivot_kernel<R, APPLY>), dim3((unsigned)gx, (unsigned)chunks), dim3(GS_THREADS),
                        lds_need, stream, X, ldx, n_rows, nc, idx8, ldi, k, n_lists, q_per_block, std_floor, mean,
-                       istd, ldo);
+                       istd, ldo, ap);
     HYPMI_HIP(hipGetLastError());
     return HYPMI_OK;
+}
+
+// rows per workgroup of the LDS-resident unmasked gather for this shape; 0: the rows do not fit
+inline int pivot_rows_per_group(int nc, int64_t n_rows) {
+    if ((int64_t)nc * 4 > MAX_LDS_BYTES) return 0;
+    int R = 1;
+    if (pivot_lds_bytes(nc, 4) <= MAX_LDS_BYTES && n_rows >= 4) R = 4;
+    else if (pivot_lds_bytes(nc, 2) <= MAX_LDS_BYTES && n_rows >= 2) R = 2;
+    return pivot_lds_bytes(nc, R) <= MAX_LDS_BYTES ? R : 0;
 }
 }  // namespace
 
@@ -1414,19 +1483,16 @@ extern "C" int hypmi_gather_stats(const float* X, int64_t n_rows, int nc, int64_
                                                      std_floor, mean, istd, ldo, stream);
     // as many rows per workgroup as LDS holds (each index fetched is reused for all of them)
     if (!mask) {
-        int R = 1;
-        if (pivot_lds_bytes(nc, 4) <= MAX_LDS_BYTES && n_rows >= 4) R = 4;
-        else if (pivot_lds_bytes(nc, 2) <= MAX_LDS_BYTES && n_rows >= 2) R = 2;
-        if (pivot_lds_bytes(nc, R) <= MAX_LDS_BYTES) {
-            if (R == 4)
-                return launch_gather_pivot<4>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, mean, istd, ldo,
-                                              stream);
-            if (R == 2)
-                return launch_gather_pivot<2>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, mean, istd, ldo,
-                                              stream);
+        const int R = pivot_rows_per_group(nc, n_rows);
+        if (R == 4)
+            return launch_gather_pivot<4>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, mean, istd, ldo,
+                                          stream);
+        if (R == 2)
+            return launch_gather_pivot<2>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, mean, istd, ldo,
+                                          stream);
+        if (R == 1)
             return launch_gather_pivot<1>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, mean, istd, ldo,
                                           stream);
-        }
         return launch_gather<1, false>(X, n_rows, nc, ldx, mask, ldm, idx_t, ldi, k, n_lists, std_floor, mean,
                                        istd, ldo, stream);
     }
@@ -1441,6 +1507,39 @@ extern "C" int hypmi_gather_stats(const float* X, int64_t n_rows, int nc, int64_
                                       ldo, stream);
     return launch_gather<1, true>(X, n_rows, nc, ldx, mask, ldm, idx_t, ldi, k, n_lists, std_floor, mean, istd, ldo,
                                   stream);
+}
+
+extern "C" int hypmi_gather_apply_supported(int nc, int64_t n_rows) {
+    return nc > 0 && nc <= 65536 && pivot_rows_per_group(nc, n_rows) != 0 ? 1 : 0;
+}
+
+extern "C" int hypmi_gather_apply(const float* X, int64_t n_rows, int nc, int64_t ldx, const uint16_t* idx_t,
+                                  int64_t ldi, int k, int64_t n_lists, float std_floor, const float* S,
+                                  int64_t lds_, const float* mt, const float* it, int64_t ldt, float* out,
+                                  int64_t ldo, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HYPMI_REQUIRE(X && idx_t && S && mt && it && out, "gather_apply: null pointer");
+    HYPMI_REQUIRE(n_rows >= 0 && nc > 0 && nc <= 65536 && ldx >= nc && k > 0 && n_lists >= 0 && ldi >= n_lists &&
+                      lds_ >= n_lists && ldo >= n_lists && ldt >= n_rows,
+                  "gather_apply: bad shape");
+    HYPMI_REQUIRE(aligned16(idx_t), "gather_apply: index lists must be 16-byte aligned");
+    if (n_rows == 0 || n_lists == 0) return HYPMI_OK;
+    const int R = pivot_rows_per_group(nc, n_rows);
+    HYPMI_REQUIRE(R != 0, "gather_apply: a cohort of %d does not fit in LDS (use gather_stats + asnorm_apply)", nc);
+    // the R statistics of a row group are read with one load
+    HYPMI_REQUIRE(ldt % R == 0 && ldt >= round_up(n_rows, R) &&
+                      (reinterpret_cast<uintptr_t>(mt) | reinterpret_cast<uintptr_t>(it)) % (4 * R) == 0,
+                  "gather_apply: T-part statistics need a leading dimension that is a multiple of %d (and covers "
+                  "the rows rounded up to it) and %d-byte alignment", R, 4 * R);
+    const ApplyArgs ap = {S, lds_, mt, it, ldt, out, ldo};
+    if (R == 4)
+        return launch_gather_pivot<4, true>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, nullptr, nullptr,
+                                            0, stream, ap);
+    if (R == 2)
+        return launch_gather_pivot<2, true>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, nullptr, nullptr,
+                                            0, stream, ap);
+    return launch_gather_pivot<1, true>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, nullptr, nullptr, 0,
+                                        stream, ap);
 }
 
 extern "C" int hypmi_gather_redo_count(unsigned long long* count, int reset) {

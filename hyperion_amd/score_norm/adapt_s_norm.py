@@ -66,6 +66,8 @@ def gather_stats(X, mask_u8, idx, n_lists, std_floor, k):
     n, nc = X.shape
     assert idx.stride(2) == 1 and idx.stride(1) == 8 and idx.shape[1] >= n_lists
     ld = engine.round_up(max(n_lists, 1), 4)
+    if ld % 512 == 0:
+        ld += 32  # the statistics are also read down their columns: no stride that maps a column to one memory channel
     mean = torch.empty((n, ld), dtype=torch.float32, device=X.device)
     istd = torch.empty((n, ld), dtype=torch.float32, device=X.device)
     _lib.check(lib.hypmi_gather_stats(engine._ptr(X), n, nc, X.stride(0),
@@ -75,6 +77,27 @@ def gather_stats(X, mask_u8, idx, n_lists, std_floor, k):
                                       float(std_floor), engine._ptr(mean), engine._ptr(istd), ld,
                                       engine.stream_ptr()))
     return mean, istd, ld
+
+
+def gather_apply_supported(nc, n_rows):
+    """Whether gather_apply can run for a cohort of nc members (its rows have to fit in LDS)."""
+    return bool(_lib.load().hypmi_gather_apply_supported(int(nc), int(n_rows)))
+
+
+def gather_apply(X, idx, n_lists, std_floor, k, S, mt, it, ldt, out):
+    """Z-part statistics of X [enrol, cohort] over the tests' lists and the normalisation in one launch:
+    out[e, t] from the raw scores S [enrol, test] and the T-part statistics mt / it [test, enrol]
+    (leading dimension ldt).  Same values as gather_stats followed by hypmi_asnorm_apply."""
+    lib = _lib.load()
+    n, nc = X.shape
+    assert idx.stride(2) == 1 and idx.stride(1) == 8 and idx.shape[1] >= n_lists
+    assert S.shape[0] == n and S.shape[1] >= n_lists and out.shape[0] == n and out.shape[1] >= n_lists
+    assert mt.shape[0] >= n_lists and it.shape[0] >= n_lists and ldt >= n
+    _lib.check(lib.hypmi_gather_apply(engine._ptr(X), n, nc, X.stride(0), engine._ptr(idx), idx.stride(0) // 8,
+                                      int(k), n_lists, float(std_floor), engine._ptr(S), S.stride(0),
+                                      engine._ptr(mt), engine._ptr(it), ldt, engine._ptr(out), out.stride(0),
+                                      engine.stream_ptr()))
+    return out
 
 
 def adapt_s_norm_device(S, A_ec, A_tc, nbest, nbest_discard, mask_ec=None, mask_tc=None,
@@ -95,8 +118,11 @@ def adapt_s_norm_device(S, A_ec, A_tc, nbest, nbest_discard, mask_ec=None, mask_
         return out[:, :nt]
     t_idx = topk_rows(A_tc, k, int(nbest_discard), exact_tc)  # per test: cohort ranked by coh-vs-test
     e_idx = topk_rows(A_ec, k, int(nbest_discard), exact_ec)  # per enrol: cohort ranked by enr-vs-coh
-    mz, iz, ldz = gather_stats(A_ec, mask_ec, t_idx, nt, std_floor, k)  # [enrol, test]
     mt, it, ldt = gather_stats(A_tc, mask_tc, e_idx, ne, std_floor, k)  # [test, enrol]
+    if mask_ec is None and gather_apply_supported(nc, ne):
+        gather_apply(A_ec, t_idx, nt, std_floor, k, S, mt, it, ldt, out)
+        return out[:, :nt]
+    mz, iz, ldz = gather_stats(A_ec, mask_ec, t_idx, nt, std_floor, k)  # [enrol, test]
     _lib.check(lib.hypmi_asnorm_apply(engine._ptr(S), S.stride(0), ne, nt, engine._ptr(mz),
                                       engine._ptr(iz), ldz, engine._ptr(mt), engine._ptr(it), ldt,
                                       engine._ptr(out), ld, engine.stream_ptr()))

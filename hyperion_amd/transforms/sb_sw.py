@@ -22,7 +22,7 @@ class SbSw(HypModel):
         """Adds the classes of (x, class_ids) to the accumulated sums; normalize() turns sums into
         the statistics (sb_sw.py:25-50; sample_weight and class_weights are accepted and unused
         there as well)."""
-        torch = engine.require_gpu()
+        engine.require_gpu()
         X = engine.upload64(x)
         n, dim = X.shape
         if self.Sb is None:
@@ -31,11 +31,14 @@ class SbSw(HypModel):
             self.mu = np.zeros((dim,))
             self.num_classes = 0
         u_ids, inv = np.unique(np.asarray(class_ids), return_inverse=True)
-        inv = torch.from_numpy(np.ascontiguousarray(inv.reshape(-1), dtype=np.int64)).cuda()
-        counts = torch.bincount(inv, minlength=len(u_ids)).to(torch.float64)
-        M = torch.zeros((len(u_ids), dim), dtype=torch.float64, device="cuda").index_add_(0, inv, X)
-        M /= counts[:, None]
-        within, _ = engine.gram64(X, (1.0 / counts)[inv])
+        inv = inv.reshape(-1)
+        counts = np.bincount(inv, minlength=len(u_ids))
+        row_w = 1.0 / counts[inv]  # every class weighs the same, whatever its size
+        order = np.argsort(inv, kind="stable").astype(np.int32)
+        offsets = np.zeros(len(u_ids) + 1, dtype=np.int64)
+        np.cumsum(counts, out=offsets[1:])
+        M = engine.pool64(X, order, offsets, row_w)  # class means: rows summed in list order
+        within, _ = engine.gram64(X, row_w)
         between, mean_sum = engine.gram64(M)
         self.num_classes += len(u_ids)
         self.mu += mean_sum.cpu().numpy()

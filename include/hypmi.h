@@ -300,6 +300,17 @@ int hypmi_asnorm_apply(const float* S, int64_t lds, int64_t ne, int64_t nt, cons
                        const float* iz, int64_t ldz, const float* mt, const float* it, int64_t ldt,
                        float* out, int64_t ldo, void* stream);
 
+/* hypmi_gather_stats (without mask) and hypmi_asnorm_apply in one launch (adapt_s_norm.py:46-63 and
+ * 88): X = enrol-vs-cohort scores [n_rows x nc], lists = the tests' cohort selections, S the raw
+ * scores [n_rows x n_lists], mt / it the T-part statistics [n_lists x n_rows] of an earlier
+ * hypmi_gather_stats over the test-vs-cohort scores; out[r,q] = the normalised score.  The Z-part
+ * statistics stay in registers.  Same bits as the two separate calls.  Only for cohorts whose rows
+ * fit in LDS: hypmi_gather_apply_supported(nc, n_rows) tells (1 / 0). */
+int hypmi_gather_apply_supported(int nc, int64_t n_rows);
+int hypmi_gather_apply(const float* X, int64_t n_rows, int nc, int64_t ldx, const uint16_t* idx, int64_t ldi,
+                       int k, int64_t n_lists, float std_floor, const float* S, int64_t lds, const float* mt,
+                       const float* it, int64_t ldt, float* out, int64_t ldo, void* stream);
+
 /* X[i,j] = 0 where mask[i,j] == 0: `scores[mask == False] = 0` (adapt_s_norm.py:37-40,
  * t_norm.py:21, z_norm.py:22), applied to the library's device copy, never to caller arrays. */
 int hypmi_mask_zero(float* X, int64_t rows, int64_t cols, int64_t ldx, const unsigned char* mask,

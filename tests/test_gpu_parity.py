@@ -926,3 +926,53 @@ def test_gather_stats_tail_selection_and_constant_members():
     ok = np.ones_like(s_ref, bool)
     ok[2, :20] = False
     assert np.max(np.abs(istd * s_ref - 1.0)[ok]) <= 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ne,nt,nc,k", [(37, 1500, 600, 50), (130, 70, 20_440, 300), (3, 2100, 30_000, 40),
+                                        (260, 1030, 4_000, 9)])
+def test_gather_apply_equals_gather_then_apply(ne, nt, nc, k):
+    """The Z-part statistics kernel that finishes the normalisation itself gives the bits of the two
+    separate launches, for every rows-per-workgroup variant and ragged shapes (row groups are
+    renumbered in sets of 128, most of which are empty here)."""
+    import torch
+
+    from hyperion_amd import _lib, engine
+    from hyperion_amd.score_norm.adapt_s_norm import gather_apply, gather_apply_supported, gather_stats, topk_rows
+
+    rng = np.random.RandomState(ne + nt)
+    A_ec = torch.from_numpy((rng.randn(ne, nc) * 5 - 8).astype(np.float32)).cuda()
+    A_tc = torch.from_numpy((rng.randn(nt, nc) * 5 - 8).astype(np.float32)).cuda()
+    S = torch.from_numpy((rng.randn(ne, nt) * 9).astype(np.float32)).cuda()
+    t_idx = topk_rows(A_tc, k, 0)
+    e_idx = topk_rows(A_ec, k, 0)
+    mz, iz, ldz = gather_stats(A_ec, None, t_idx, nt, 1e-5, k)
+    mt, it, ldt = gather_stats(A_tc, None, e_idx, ne, 1e-5, k)
+    ld = engine.round_up(nt, 32)
+    ref = torch.full((ne, ld), 7.0, dtype=torch.float32, device="cuda")
+    lib = _lib.load()
+    _lib.check(lib.hypmi_asnorm_apply(engine._ptr(S), S.stride(0), ne, nt, engine._ptr(mz), engine._ptr(iz), ldz,
+                                      engine._ptr(mt), engine._ptr(it), ldt, engine._ptr(ref), ld,
+                                      engine.stream_ptr()))
+    assert gather_apply_supported(nc, ne)
+    out = torch.full((ne, ld), 7.0, dtype=torch.float32, device="cuda")
+    gather_apply(A_ec, t_idx, nt, 1e-5, k, S, mt, it, ldt, out)
+    assert torch.equal(out, ref)  # including the untouched padding columns
+    assert not gather_apply_supported(45_000, ne)
+
+
+@pytest.mark.gpu
+def test_backend_fused_and_separate_normalisation_agree():
+    import synth
+    from hyperion_amd.backend import PLDABackend
+    from hyperion_amd.pdfs.plda import SPLDA
+
+    m = synth.make_splda(40, 12)
+    xe, _ = synth.raw_xvectors(300, d=40, seed=21, num_centers=30)
+    xt, _ = synth.raw_xvectors(700, d=40, seed=22, num_centers=30)
+    xc, _ = synth.raw_xvectors(400, d=40, seed=23, num_centers=200)
+    be = PLDABackend(SPLDA(mu=m["mu"], V=m["V"], W=m["W"]), None, nbest=50, test_chunk=512)
+    coh = be.prepare_cohort(xe, xc)
+    fused = be.score_snorm(xt, coh).cpu().numpy()
+    be.fuse_apply = False
+    assert np.array_equal(be.score_snorm(xt, coh).cpu().numpy(), fused)
