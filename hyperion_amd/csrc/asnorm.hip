@@ -346,6 +346,17 @@ __device__ __forceinline__ unsigned lanes_below(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
+// What select() can tell about the fp32 uncertainty band [t - delta, t + delta] around the key t it
+// returns, from the bracket candidates every wave holds anyway: if the band lies inside the bracket,
+// `in_band` is the number of keys in it (t itself included).  One key in the band means there is
+// nothing to re-decide and the scan of all ITEMS keys for band members is not needed.
+struct BandProbe {
+    int mode;      // 0: no probe; 1: delta = |t| * 2.4e-7; 2: delta = 2 * bound
+    float bound;
+    bool known;    // out: the band lies inside the bracket of candidates
+    int in_band;   // out: keys with t - delta <= value <= t + delta (valid when known)
+};
+
 template <int ITEMS>
 struct TopkRegs {
     unsigned key[ITEMS];
@@ -362,7 +373,8 @@ struct TopkRegs {
 
     // Key T at descending rank `want` (0-based), the number of keys > T and the number == T.
     __device__ __forceinline__ void select(int want, int nc, TopkShared& sh, int& par, int tid, unsigned* out_key,
-                                           int* out_gt, int* out_eq) {
+                                           int* out_gt, int* out_eq, BandProbe* band = nullptr) {
+        if (band) band->known = false;
         const int lane = tid & 63, wave = tid >> 6;
         unsigned prefix = 0;
         int c_lo = nc;  // keys >= prefix
@@ -382,6 +394,7 @@ struct TopkRegs {
         if (b >= 0) {
             // bracket [prefix, prefix + 2^(b+1)) holds c_lo - c_hi <= 1024 keys: move them to registers
             const unsigned width = b == 31 ? 0u : (1u << (b + 1));  // b < 31 here
+            const unsigned bracket_lo = prefix;
             if (tid == 0) sh.ncand = 0;
             __syncthreads();
             auto inside = [prefix, width](unsigned kx) { return kx != 0 && kx - prefix < width; };  // key 0 = no element
@@ -423,6 +436,24 @@ struct TopkRegs {
                 } else {
                     c_hi = c;
                 }
+            }
+            if (band && band->mode != 0) {
+                // the same float comparisons as the full scan, over the candidates only
+                const float thr = float_of_key(prefix);
+                const float delta = band->mode == 1 ? fabsf(thr) * 2.4e-7f : 2.f * band->bound;
+                const float hi = thr + delta, lo = thr - delta;
+                const unsigned first = bracket_lo == 0 ? 1u : bracket_lo, last_key = bracket_lo | (width - 1u);
+                // finite band whose ends map into the bracket (keys are monotone in the value)
+                // (a band end of zero is left to the full scan: -0 and +0 compare equal but have two keys)
+                band->known = delta >= 0.f && fabsf(hi) <= 3.402823466e38f && fabsf(lo) <= 3.402823466e38f &&
+                              hi != 0.f && lo != 0.f && key_of(lo) >= first && key_of(hi) <= last_key;
+                unsigned wb = 0;
+#pragma unroll
+                for (int u = 0; u < TR_CAND / 64; ++u) {
+                    const float v = float_of_key(ck[u]);
+                    wb += mask_count(__ballot(ck[u] != 0 && v >= lo && !(v > hi)));
+                }
+                band->in_band = (int)wb;
             }
         }
         *out_key = prefix;
@@ -470,8 +501,15 @@ __global__ __launch_bounds__(TR_THREADS) void topk_rows_reg_kernel(const float* 
     const bool use_lo = discard > 0;
     unsigned key_hi, key_lo = 0xffffffffu;
     int gt_hi, eq_hi, gt_lo = 0, eq_lo = 0;
-    R.select(last - 1, nc, sh, par, tid, &key_hi, &gt_hi, &eq_hi);
-    if (use_lo) R.select(discard - 1, nc, sh, par, tid, &key_lo, &gt_lo, &eq_lo);
+    BandProbe probe_hi = {0, 0.f, false, 0}, probe_lo = {0, 0.f, false, 0};
+    if (ex.mode != 0) {
+        probe_hi.mode = probe_lo.mode = ex.mode;
+        if (ex.mode == 2)
+            probe_hi.bound = probe_lo.bound =
+                ex.err_coeff * (ex.bnd_rows[2 * row] * ex.coh_gmax + ex.bnd_rows[2 * row + 1] + ex.coh_qmax);
+    }
+    R.select(last - 1, nc, sh, par, tid, &key_hi, &gt_hi, &eq_hi, &probe_hi);
+    if (use_lo) R.select(discard - 1, nc, sh, par, tid, &key_lo, &gt_lo, &eq_lo, &probe_lo);
 
     // what fp32 cannot resolve around a boundary value: re-decide those entries from float64 values
     int n_hi = 0, n_lo = 0;
@@ -483,13 +521,14 @@ __global__ __launch_bounds__(TR_THREADS) void topk_rows_reg_kernel(const float* 
             d_hi = fabsf(thr_hi) * 2.4e-7f;
             d_lo = fabsf(thr_lo) * 2.4e-7f;
         } else {
-            const float bound = ex.err_coeff * (ex.bnd_rows[2 * row] * ex.coh_gmax + ex.bnd_rows[2 * row + 1] +
-                                                ex.coh_qmax);
-            d_hi = d_lo = 2.f * bound;
+            d_hi = d_lo = 2.f * probe_hi.bound;
         }
         // Entries above thr + delta are certainly above the boundary "rank < Rk"; m = Rk - (their
         // count) of the candidates within +-delta must be above, chosen by exact value (ties by index).
-        auto redecide = [&](int Rk, float thr, float delta, unsigned short* cidx, unsigned char* cabove) -> int {
+        auto redecide = [&](int Rk, float thr, float delta, unsigned short* cidx, unsigned char* cabove,
+                            const BandProbe& probe) -> int {
+            // the boundary key alone in its band (the same in every wave): nothing to decide
+            if (probe.known && probe.in_band <= 1) return 0;
             if (tid == 0) sh.ncand = 0;
             const float hi = thr + delta, lo = thr - delta;
             __syncthreads();  // ncand is cleared before anyone appends
@@ -546,8 +585,8 @@ __global__ __launch_bounds__(TR_THREADS) void topk_rows_reg_kernel(const float* 
             if (tid == 0 && ex.counters) atomicAdd(&ex.counters[0], 1ull);
             return n_cand;
         };
-        n_hi = redecide(last, thr_hi, d_hi, cand_idx, cand_above);
-        if (use_lo) n_lo = redecide(discard, thr_lo, d_lo, cand_idx + TK_CAND, cand_above + TK_CAND);
+        n_hi = redecide(last, thr_hi, d_hi, cand_idx, cand_above, probe_hi);
+        if (use_lo) n_lo = redecide(discard, thr_lo, d_lo, cand_idx + TK_CAND, cand_above + TK_CAND, probe_lo);
     }
 
     // Ordered positions.  Index order is item-major (i = j * 256 + tid), so the number of flagged
@@ -627,13 +666,28 @@ __global__ __launch_bounds__(TR_THREADS) void topk_rows_reg_kernel(const float* 
     for (int w = 0; w < SELW; ++w) above_hi[w] = above_lo[w] = valid[w] = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) opaque(R.key[j]);
+    if (!order_hi && !use_lo) {
+        // the usual case -- one boundary, all its ties accepted: a member is a key >= the boundary key
+        // (which is at least 1, so "no element" never qualifies); bits shifted in from the top item down
+        const unsigned kb = (unsigned)__builtin_amdgcn_readfirstlane((int)key_hi);
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const unsigned kx = R.key[j];
-        const unsigned bit = 1u << (j & 31);
-        if (kx > key_hi || (kx == key_hi && (hi_in[j >> 5] & bit))) above_hi[j >> 5] |= bit;
-        if (use_lo && (kx > key_lo || (kx == key_lo && (lo_in[j >> 5] & bit)))) above_lo[j >> 5] |= bit;
-        if (kx != 0) valid[j >> 5] |= bit;
+        for (int w = 0; w < SELW; ++w) {
+            unsigned bits = 0;
+#pragma unroll
+            for (int j = (32 * w + 31 < ITEMS ? 32 * w + 31 : ITEMS - 1); j >= 32 * w; --j)
+                bits = (bits << 1) | (R.key[j] >= kb ? 1u : 0u);
+            above_hi[w] = bits;
+            valid[w] = 0xffffffffu;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const unsigned kx = R.key[j];
+            const unsigned bit = 1u << (j & 31);
+            if (kx > key_hi || (kx == key_hi && (hi_in[j >> 5] & bit))) above_hi[j >> 5] |= bit;
+            if (use_lo && (kx > key_lo || (kx == key_lo && (lo_in[j >> 5] & bit)))) above_lo[j >> 5] |= bit;
+            if (kx != 0) valid[j >> 5] |= bit;
+        }
     }
     // re-decided boundary candidates override the fp32 decision of their owner (item i / 256 of thread i % 256)
     auto override_bits = [&](int n, const unsigned short* cidx, const unsigned char* cabove, unsigned (&bits)[SELW]) {
