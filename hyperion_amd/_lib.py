@@ -40,6 +40,9 @@ class TopkExact(ctypes.Structure):
         ("coh_qmax", ctypes.c_float),
         ("err_coeff", ctypes.c_float),
         ("counters", c_void_p),
+        ("row_map", c_void_p),
+        ("todo", c_void_p),
+        ("todo_count", c_void_p),
     ]
 
 
@@ -77,6 +80,8 @@ SIGNATURES = {
     "hypmi_prologue_pairs_supported": (ctypes.c_int, [c_void_p]),
     "hypmi_prologue_pairs": (ctypes.c_int, [c_void_p, c_void_p, i64, i64, ctypes.c_int, c_void_p, c_void_p,
                                             c_void_p, c_void_p, i64, c_void_p]),
+    "hypmi_prologue_pairs_bounds": (ctypes.c_int, [c_void_p, c_void_p, i64, i64, ctypes.c_int, c_void_p, c_void_p,
+                                                   c_void_p, c_void_p, c_void_p, i64, c_void_p]),
     "hypmi_prologue_noalloc_max_rows": (i64, [c_void_p]),
     "hypmi_prologue_noalloc": (ctypes.c_int, [c_void_p, c_void_p, i64, i64, ctypes.c_int, c_void_p, c_void_p]),
     "hypmi_transform": (ctypes.c_int, [c_void_p, c_void_p, i64, i64, c_void_p, i64, c_void_p, i64,

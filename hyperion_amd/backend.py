@@ -61,6 +61,18 @@ def all_gather_lists(local, counts, group=None):
     return torch.cat([recv[r, :, :counts[r]] for r in range(world)], dim=1).contiguous()
 
 
+LAZY_MAX_COHORT = 40_960  # largest cohort the register-resident top-k kernel takes
+
+
+def _take64(x, lo, hi, rows):
+    """Rows `rows` (device int32, relative to lo) of x[lo:hi] as device float64, from the caller's own
+    array (a float64 host array keeps the digits its fp32 device copy lost)."""
+    torch = engine.require_gpu()
+    if isinstance(x, torch.Tensor):
+        return engine.upload64(x[lo:hi][rows.long()])
+    return engine.upload64(np.asarray(x)[lo:hi][rows.cpu().numpy()])
+
+
 def _rows(G, r0, r1):
     """Rows r0..r1-1 of packed rows in either form (fp32 matrix or SplitRows)."""
     return G.rows(r0, r1) if isinstance(G, engine.SplitRows) else G[r0:r1]
@@ -83,6 +95,8 @@ class PLDABackend:
         self.tile_bytes = 96 << 30
         # finish the normalisation inside the Z-part statistics kernel (no separate apply pass)
         self.fuse_apply = True
+        # float64 rows for the exact top-k only where a boundary is in doubt (False: for every vector)
+        self.lazy_exact = True
         # re-decide top-k members that fp32 cannot separate from the selection boundary with fp64
         # scores (costs one fp64 prologue per vector; without it ~0.05 % of test columns pick one
         # different cohort member than float64 arithmetic would)
@@ -139,8 +153,17 @@ class PLDABackend:
         panel A_ec [n_enrol, n_cohort] and the per-enrolment top-k cohort lists.  With world > 1 each
         rank selects the lists of its own slice of enrolment rows and one all-gather makes them
         global (the only inter-GPU exchange of the whole pipeline)."""
-        Ge = self._timed("prologue", lambda: self.embed(x_enrol, SIDE_ENROL))
         xc = engine.upload(x_cohort)
+        nc_all = xc.shape[0]
+        # fp64 rows only for the rows whose top-k boundary is in doubt (see topk_rows): needs the bounds
+        # the pair-writing prologue kernel gives and the register-resident selection kernel
+        lazy = self.exact_topk and self.lazy_exact and self.plan.pairs_in_prologue() and nc_all <= LAZY_MAX_COHORT
+        xe = engine.upload(x_enrol)
+        be_rows = None
+        if lazy:
+            Ge, be_rows = self._timed("prologue", lambda: self.plan.prologue_split(xe, SIDE_ENROL, bounds=True))
+        else:
+            Ge = self._timed("prologue", lambda: self.plan.prologue_split(xe, SIDE_ENROL))
         Gc_test = self._timed("prologue", lambda: self.plan.prologue_split(xc, SIDE_TEST))
         A_ec = self._timed("score_enrol_cohort", lambda: engine.score(Ge, Gc_test))
         ne, nc = A_ec.shape
@@ -160,14 +183,17 @@ class PLDABackend:
             Gc64, bc = self.plan.prologue_f64(engine.upload64(x_cohort), SIDE_TEST)
             coh64 = {"G_coh": Gc64, "coh_gmax": float(bc[:, 0].max()), "coh_qmax": float(bc[:, 1].max()),
                      "counters_dev": self.topk_counters}
-            xe64 = engine.upload64(x_enrol[lo:hi])
-            Ge64, be = self.plan.prologue_f64(xe64, SIDE_ENROL)
-            exact = dict(coh64, G_rows=Ge64, bnd_rows=be)
+            if lazy:
+                exact = dict(coh64, bnd_rows=be_rows[lo:hi].contiguous(),
+                             rows64=lambda rows: self.plan.prologue_f64(_take64(x_enrol, lo, hi, rows), SIDE_ENROL))
+            else:
+                Ge64, be = self.plan.prologue_f64(engine.upload64(x_enrol[lo:hi]), SIDE_ENROL)
+                exact = dict(coh64, G_rows=Ge64, bnd_rows=be)
         local = self._timed("topk_enrol", lambda: topk_rows(A_ec[lo:hi], k, self.nbest_discard, exact))
         local = local[:, :hi - lo]  # [k/8, rows, 8]
         e_idx = all_gather_lists(local.reshape(local.shape[0], -1), counts, group)
         e_idx = e_idx.reshape(e_idx.shape[0], -1, 8).contiguous()
-        return {"Ge": Ge, "Gc_test": Gc_test, "A_ec": A_ec, "e_idx": e_idx, "k": k, "coh64": coh64}
+        return {"Ge": Ge, "Gc_test": Gc_test, "A_ec": A_ec, "e_idx": e_idx, "k": k, "coh64": coh64, "lazy": lazy}
 
     def score_snorm(self, x_test, cohort, out=None, reduce=None):
         """AS-normalised scores of every enrolment model against `x_test` (this rank's shard).
@@ -196,10 +222,15 @@ class PLDABackend:
             xc = xt[c0:c1]
             T = self._timed
             # tests as rows of the cohort panel and as columns of the trial matrix
-            Gt_rows, Gt_cols = T("prologue", lambda: self.plan.prologue_split_both(xc))
-            A_tc = T("score_test_cohort", lambda: engine.score(Gt_rows, cohort["Gc_test"]))  # [chunk, cohort]
             exact = None
-            if cohort.get("coh64") is not None:
+            if cohort.get("coh64") is not None and cohort.get("lazy"):
+                Gt_rows, Gt_cols, bt = T("prologue", lambda: self.plan.prologue_split_both(xc, bounds=True))
+                exact = dict(cohort["coh64"], bnd_rows=bt,
+                             rows64=lambda rows: self.plan.prologue_f64(_take64(x_test, c0, c1, rows), SIDE_ENROL))
+            else:
+                Gt_rows, Gt_cols = T("prologue", lambda: self.plan.prologue_split_both(xc))
+            A_tc = T("score_test_cohort", lambda: engine.score(Gt_rows, cohort["Gc_test"]))  # [chunk, cohort]
+            if cohort.get("coh64") is not None and exact is None:
                 def f64_rows():
                     Gt64, bt = self.plan.prologue_f64(engine.upload64(x_test[c0:c1]), SIDE_ENROL)
                     return dict(cohort["coh64"], G_rows=Gt64, bnd_rows=bt)

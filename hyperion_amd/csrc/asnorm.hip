@@ -102,6 +102,12 @@ struct ExactSrc {
     const float* bnd_rows;  // mode 2: (|g|, |q|) per row
     float coh_gmax, coh_qmax, err_coeff;
     unsigned long long* counters;  // [0] rows with a re-decided boundary, [1] rows skipped (too many ties)
+    // mode 3 (register-resident kernel only): no exact values yet -- rows whose boundary band holds more
+    // than the boundary key itself are appended to `todo` (their count in *todo_count) for a second call
+    const int* row_map;      // optional: workgroup b handles row row_map[b] of A and of the lists, with
+                             // exact values and bounds taken from row b of G_rows / bnd_rows
+    int* todo;
+    unsigned* todo_count;
 };
 
 constexpr int TK_CAND = 64;  // boundary candidates re-decided per boundary
@@ -289,11 +295,14 @@ __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float* __re
 // ITEMS registers (no LDS copy of the row, no atomics on it).  The key at descending rank `want` is
 // found bit by bit from the top: the answer has bit b set iff more than `want` keys are
 // >= (prefix | 1 << b).  One step is ITEMS compares per thread, a ballot count per wave and one
-// barrier.  As soon as at most 1024 keys are left inside the bracket [prefix, prefix + 2^b) they are
-// copied into four registers per thread and the remaining steps cost four compares.  Four such
-// workgroups share a CU, so the barriers of one overlap the compares of the others.
+// barrier.  As soon as at most TR_CAND keys are left inside the bracket [prefix, prefix + 2^b) they are
+// copied to LDS, every wave takes all of them (TR_CAND / 64 registers per lane) and finishes the
+// remaining bits on its own without barriers.  (512 measured best for 20 000-member rows: 1024 doubles
+// the compares of the ~28 remaining steps, 256 costs two more full passes and more often leaves the
+// uncertainty band of the boundary outside the bracket.)  Several such workgroups share a CU, so the
+// barriers of one overlap the compares of the others.
 constexpr int TR_THREADS = 256, TR_WAVES = TR_THREADS / 64;
-constexpr int TR_CAND = 1024;     // the bracket is narrow once it holds at most this many keys
+constexpr int TR_CAND = 512;     // the bracket is narrow once it holds at most this many keys
 constexpr int TR_STAGE = 8192;    // longest list staged in LDS before it is written (entries)
 constexpr int TR_ORDER = 2048;    // longest list that leaves ordered by LDS bank class
 constexpr int TR_MAX_ITEMS = 160;
@@ -392,7 +401,7 @@ struct TopkRegs {
             }
         }
         if (b >= 0) {
-            // bracket [prefix, prefix + 2^(b+1)) holds c_lo - c_hi <= 1024 keys: move them to registers
+            // bracket [prefix, prefix + 2^(b+1)) holds c_lo - c_hi <= TR_CAND keys: move them to registers
             const unsigned width = b == 31 ? 0u : (1u << (b + 1));  // b < 31 here
             const unsigned bracket_lo = prefix;
             if (tid == 0) sh.ncand = 0;
@@ -477,7 +486,8 @@ __global__ __launch_bounds__(TR_THREADS) void topk_rows_reg_kernel(const float* 
     __shared__ unsigned short bank_cnt[8][32];
     __shared__ unsigned short bank_start[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t row = blockIdx.x;
+    const int64_t xrow = blockIdx.x;  // row of the exact values and bounds
+    const int64_t row = ex.row_map ? ex.row_map[xrow] : xrow;
     int par = 0;
     TopkRegs<ITEMS> R;
     const float* src = A + row * lda;
@@ -503,10 +513,10 @@ __global__ __launch_bounds__(TR_THREADS) void topk_rows_reg_kernel(const float* 
     int gt_hi, eq_hi, gt_lo = 0, eq_lo = 0;
     BandProbe probe_hi = {0, 0.f, false, 0}, probe_lo = {0, 0.f, false, 0};
     if (ex.mode != 0) {
-        probe_hi.mode = probe_lo.mode = ex.mode;
-        if (ex.mode == 2)
+        probe_hi.mode = probe_lo.mode = ex.mode == 1 ? 1 : 2;
+        if (ex.mode != 1)
             probe_hi.bound = probe_lo.bound =
-                ex.err_coeff * (ex.bnd_rows[2 * row] * ex.coh_gmax + ex.bnd_rows[2 * row + 1] + ex.coh_qmax);
+                ex.err_coeff * (ex.bnd_rows[2 * xrow] * ex.coh_gmax + ex.bnd_rows[2 * xrow + 1] + ex.coh_qmax);
     }
     R.select(last - 1, nc, sh, par, tid, &key_hi, &gt_hi, &eq_hi, &probe_hi);
     if (use_lo) R.select(discard - 1, nc, sh, par, tid, &key_lo, &gt_lo, &eq_lo, &probe_lo);
@@ -514,7 +524,12 @@ __global__ __launch_bounds__(TR_THREADS) void topk_rows_reg_kernel(const float* 
     // what fp32 cannot resolve around a boundary value: re-decide those entries from float64 values
     int n_hi = 0, n_lo = 0;
     float thr_hi = 0.f, thr_lo = 0.f, d_hi = 0.f, d_lo = 0.f;
-    if (ex.mode != 0) {
+    if (ex.mode == 3) {
+        // first of two calls: only note the rows that need exact values
+        const bool settled = probe_hi.known && probe_hi.in_band <= 1 &&
+                             (!use_lo || (probe_lo.known && probe_lo.in_band <= 1));
+        if (!settled && tid == 0) ex.todo[atomicAdd(ex.todo_count, 1u)] = (int)row;
+    } else if (ex.mode != 0) {
         thr_hi = float_of_key(key_hi);
         thr_lo = float_of_key(key_lo);
         if (ex.mode == 1) {  // the fp32 matrix is the rounding of the fp64 one
@@ -560,7 +575,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_rows_reg_kernel(const float* 
                 if (tid < n_cand) exact_s[tid] = ex.A64[row * ex.lda64 + cidx[tid]];
             } else {
                 const int grp = tid >> 4, sub = tid & 15;
-                const double* gr = ex.G_rows + row * ex.ldg;
+                const double* gr = ex.G_rows + xrow * ex.ldg;
                 for (int a2 = grp; a2 < n_cand; a2 += TR_THREADS / 16) {
                     const double* gc = ex.G_coh + (int64_t)cidx[a2] * ex.ldg;
                     double acc = 0.0;
@@ -1408,14 +1423,20 @@ extern "C" int hypmi_topk_rows(const float* A, int64_t n_rows, int nc, int64_t l
     HYPMI_REQUIRE(aligned16(idx_t), "topk_rows: index lists must be 16-byte aligned");
     ExactSrc ex = {};
     if (exact && exact->mode != 0) {
-        HYPMI_REQUIRE(exact->mode == 1 || exact->mode == 2, "topk_rows: unknown exact mode %d", exact->mode);
+        HYPMI_REQUIRE(exact->mode >= 1 && exact->mode <= 3, "topk_rows: unknown exact mode %d", exact->mode);
         if (exact->mode == 1) {
             HYPMI_REQUIRE(exact->A64 && exact->lda64 >= nc, "topk_rows: exact matrix missing or too narrow");
-        } else {
+        } else if (exact->mode == 2) {
             HYPMI_REQUIRE(exact->G_rows && exact->G_coh && exact->bnd_rows && exact->K > 0 &&
                               exact->ldg >= exact->K + 2,
                           "topk_rows: exact packed rows missing");
+        } else {
+            HYPMI_REQUIRE(exact->bnd_rows && exact->todo && exact->todo_count,
+                          "topk_rows: mode 3 needs the rows' bounds and the list of rows to fill");
+            HYPMI_REQUIRE(nc <= TR_MAX_NC, "topk_rows: mode 3 is for cohorts of up to %d members", TR_MAX_NC);
         }
+        HYPMI_REQUIRE(!exact->row_map || (exact->mode == 2 && nc <= TR_MAX_NC),
+                      "topk_rows: a row map goes with mode 2 and cohorts of up to %d members", TR_MAX_NC);
         ex.mode = exact->mode;
         ex.A64 = exact->A64;
         ex.lda64 = exact->lda64;
@@ -1428,6 +1449,9 @@ extern "C" int hypmi_topk_rows(const float* A, int64_t n_rows, int nc, int64_t l
         ex.coh_qmax = exact->coh_qmax;
         ex.err_coeff = exact->err_coeff;
         ex.counters = exact->counters;
+        ex.row_map = exact->row_map;
+        ex.todo = exact->todo;
+        ex.todo_count = exact->todo_count;
     }
     if (n_rows == 0) return HYPMI_OK;
     if (nc <= TR_MAX_NC) {  // keys in registers

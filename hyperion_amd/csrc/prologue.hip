@@ -376,6 +376,8 @@ struct PairTail {
     uint4* H;        // [n x row_slots] fp16 pairs of side `side`
     uint4* H_other;  // optional: the same rows packed for the other side of a trial
     float* G;        // optional [n x KP] packed fp32 rows of side `side` (nullptr: not wanted)
+    float* bnd;      // optional [n x 2]: (|g|, |q (+ c on the test side)|) of side `side`, the terms of the
+                     // fp32 error bound of a score against this row
 };
 
 template <int TM, bool PAIRS = false>
@@ -482,7 +484,12 @@ __global__ __launch_bounds__(256) void prologue_fused_kernel(
                 sh += hv * hv;
                 z[k] = gv;
             }
-            const double q = 0.5 * (wave_sum(sg) - wave_sum(sh));
+            const double tg = wave_sum(sg);
+            const double q = 0.5 * (tg - wave_sum(sh));
+            if (pt.bnd && lane == 0 && m0 + rr < n) {
+                pt.bnd[2 * (m0 + rr)] = (float)sqrt(tg);
+                pt.bnd[2 * (m0 + rr) + 1] = (float)fabs(pt.side == HYPMI_SIDE_TEST ? q + pt.c : q);
+            }
             // coordinates K, K + 1 depend on the side ([q, 1] or [1, q + c]): both q's are kept, the
             // test side's in the spare column behind the row
             for (int k = K + lane; k <= KP; k += 64) z[k] = k == K ? (float)q : (k == KP ? (float)(q + pt.c) : 0.f);
@@ -544,7 +551,7 @@ int run_fused_tail(const hypmi_plan* p, const float* in, int64_t ldin, int64_t r
 
 // The fused tail with the packing and the fp16-pair conversion in its epilogue (shared-basis plans).
 int run_fused_tail_pairs(const hypmi_plan* p, const float* in, int64_t ldin, int64_t rows, int side, void* H,
-                         void* H_other, float* G, hipStream_t stream) {
+                         void* H_other, float* G, float* bnd, hipStream_t stream) {
     const FusedTail& f = p->fused;
     PairTail pt;
     pt.col_map = p->col_map;
@@ -556,6 +563,7 @@ int run_fused_tail_pairs(const hypmi_plan* p, const float* in, int64_t ldin, int
     pt.H = static_cast<uint4*>(H);
     pt.H_other = static_cast<uint4*>(H_other);
     pt.G = G;
+    pt.bnd = bnd;
     const int lds1 = 64 * (p->KP + 1) * (int)sizeof(float), lds2 = 2 * lds1;
     const bool big = rows >= 128 * 2048 && lds2 <= 96 * 1024;
     if (big) {
@@ -774,8 +782,18 @@ extern "C" int hypmi_prologue_pairs_supported(const hypmi_plan* p) {
     return (p && p->K > 0 && p->fused.enabled && p->shared && p->col_map && p->KP % 8 == 0 && p->KP <= 320) ? 1 : 0;
 }
 
+extern "C" int hypmi_prologue_pairs_bounds(const hypmi_plan* p, const float* x, int64_t n, int64_t ldx, int side,
+                                           void* H, void* H_other, float* G, float* bnd, void* ws,
+                                           int64_t ws_bytes, void* stream_);
+
 extern "C" int hypmi_prologue_pairs(const hypmi_plan* p, const float* x, int64_t n, int64_t ldx, int side,
                                     void* H, void* H_other, float* G, void* ws, int64_t ws_bytes, void* stream_) {
+    return hypmi_prologue_pairs_bounds(p, x, n, ldx, side, H, H_other, G, nullptr, ws, ws_bytes, stream_);
+}
+
+extern "C" int hypmi_prologue_pairs_bounds(const hypmi_plan* p, const float* x, int64_t n, int64_t ldx, int side,
+                                           void* H, void* H_other, float* G, float* bnd, void* ws,
+                                           int64_t ws_bytes, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     HYPMI_REQUIRE(hypmi_prologue_pairs_supported(p),
                   "prologue_pairs: this plan has no fused shared-basis tail; use hypmi_prologue + hypmi_pair_rows");
@@ -802,7 +820,7 @@ extern "C" int hypmi_prologue_pairs(const hypmi_plan* p, const float* x, int64_t
         if (rc != HYPMI_OK) return rc;
         rc = run_fused_tail_pairs(p, cur, ldcur, rows, side, static_cast<char*>(H) + r0 * row_bytes,
                                   H_other ? static_cast<char*>(H_other) + r0 * row_bytes : nullptr,
-                                  G ? G + r0 * p->KP : nullptr, stream);
+                                  G ? G + r0 * p->KP : nullptr, bnd ? bnd + 2 * r0 : nullptr, stream);
         if (rc != HYPMI_OK) return rc;
     }
     return HYPMI_OK;

@@ -310,11 +310,13 @@ class Plan:
                                             _ptr(ws), nbytes, stream_ptr()))
         return G
 
-    def prologue_split(self, x, side, fmt=None, keep_rows=False):
+    def prologue_split(self, x, side, fmt=None, keep_rows=False, bounds=False):
         """x -> the operand of the 16-bit score kernels (SplitRows).  Plans with a fused shared-basis
         tail and the default fp16-pair format do it in the prologue kernel itself (one launch, the
         packed fp32 rows never reach memory unless keep_rows asks for them too: then (split, G)
-        is returned); other plans, formats or widths convert the packed rows in a second kernel."""
+        is returned); other plans, formats or widths convert the packed rows in a second kernel.
+        bounds (only with pairs_in_prologue): also the device [n, 2] floats (|g|, |q|) of the rows, as
+        the last element of the result."""
         torch = _torch()
         fmt = fmt or DEFAULT_SPLIT
         self._check_x(x)
@@ -322,34 +324,52 @@ class Plan:
         if fmt == "pair" and n and self._lib.hypmi_prologue_pairs_supported(self._h):
             H = torch.empty(self._lib.hypmi_pair_bytes(self.kp, n) // 4, dtype=torch.int32, device=x.device)
             G = torch.empty((n, self.kp), dtype=torch.float32, device=x.device) if keep_rows else None
+            bnd = torch.empty((n, 2), dtype=torch.float32, device=x.device) if bounds else None
             ws, nbytes = self._workspace(n)
-            _lib.check(self._lib.hypmi_prologue_pairs(self._h, _ptr(x), n, x.stride(0), int(side), _ptr(H), None,
-                                                      _ptr(G) if keep_rows else None, _ptr(ws), nbytes,
-                                                      stream_ptr()))
+            _lib.check(self._lib.hypmi_prologue_pairs_bounds(self._h, _ptr(x), n, x.stride(0), int(side), _ptr(H),
+                                                             None, _ptr(G) if keep_rows else None,
+                                                             _ptr(bnd) if bounds else None, _ptr(ws), nbytes,
+                                                             stream_ptr()))
             split = SplitRows(H, n, self.kp, fmt)
-            return (split, G) if keep_rows else split
+            res = (split, G) if keep_rows else (split,)
+            if bounds:
+                res = res + (bnd,)
+            return res if len(res) > 1 else split
+        if bounds:
+            raise ValueError("bounds come from the prologue kernel that writes fp16 pairs (pairs_in_prologue)")
         G = self.prologue(x, side)
         split = split_rows(G, fmt)
         if split is None:  # no 16-bit kernel for this width: the fp32 rows are the operand
             return (G, G) if keep_rows else G
         return (split, G) if keep_rows else split
 
-    def prologue_split_both(self, x, fmt=None):
+    def pairs_in_prologue(self, fmt=None):
+        """Whether the prologue kernel of this plan writes the fp16-pair operand itself."""
+        return (fmt or DEFAULT_SPLIT) == "pair" and bool(self._lib.hypmi_prologue_pairs_supported(self._h))
+
+    def prologue_split_both(self, x, fmt=None, bounds=False):
         """x -> (enrol-side, test-side) score operands of the same vectors (adaptive S-norm uses a test
         vector as a row of the cohort panel and as a column of the trial matrix).  One pass over the
-        chain where the plan's prologue kernel writes fp16 pairs itself, two otherwise."""
+        chain where the plan's prologue kernel writes fp16 pairs itself, two otherwise.  bounds (only
+        with pairs_in_prologue): a third result, device [n, 2] floats (|g|, |q|) of the enrol-side rows
+        (see prologue_f64)."""
         torch = _torch()
         fmt = fmt or DEFAULT_SPLIT
         self._check_x(x)
         n = x.shape[0]
-        if fmt == "pair" and n and self._lib.hypmi_prologue_pairs_supported(self._h):
+        if self.pairs_in_prologue(fmt) and n:
             nb = self._lib.hypmi_pair_bytes(self.kp, n) // 4
             He = torch.empty(nb, dtype=torch.int32, device=x.device)
             Ht = torch.empty(nb, dtype=torch.int32, device=x.device)
+            bnd = torch.empty((n, 2), dtype=torch.float32, device=x.device) if bounds else None
             ws, nbytes = self._workspace(n)
-            _lib.check(self._lib.hypmi_prologue_pairs(self._h, _ptr(x), n, x.stride(0), SIDE_ENROL, _ptr(He),
-                                                      _ptr(Ht), None, _ptr(ws), nbytes, stream_ptr()))
-            return SplitRows(He, n, self.kp, fmt), SplitRows(Ht, n, self.kp, fmt)
+            _lib.check(self._lib.hypmi_prologue_pairs_bounds(self._h, _ptr(x), n, x.stride(0), SIDE_ENROL, _ptr(He),
+                                                             _ptr(Ht), None, _ptr(bnd) if bounds else None,
+                                                             _ptr(ws), nbytes, stream_ptr()))
+            res = SplitRows(He, n, self.kp, fmt), SplitRows(Ht, n, self.kp, fmt)
+            return res + (bnd,) if bounds else res
+        if bounds:
+            raise ValueError("bounds come from the prologue kernel that writes fp16 pairs (pairs_in_prologue)")
         return self.prologue_split(x, SIDE_ENROL, fmt), self.prologue_split(x, SIDE_TEST, fmt)
 
     def prologue_f64(self, x64, side):

@@ -12,6 +12,11 @@ def topk_rows(A, k, discard, exact=None):
     exact: optional source of float64 values used to re-decide members that fp32 cannot separate
     from a selection boundary: {"A64": float64 device matrix A was rounded from} or
     {"G_rows", "G_coh", "bnd_rows", "coh_gmax", "coh_qmax"} (fp64 packed rows of Plan.prologue_f64).
+    Instead of "G_rows" the dict may hold "rows64", a function (device int32 row numbers) ->
+    (fp64 packed rows, bounds) of just those rows, and "bnd_rows" from the fp32 prologue
+    (Plan.prologue_split(..., bounds=True)): the fp64 rows are then made only for the few per cent of
+    rows whose boundary has a second score inside its fp32 uncertainty band (one host read of their
+    count in between; the dict receives "redone" = that count).
     With exact["count"] = True the dict receives "counters" = (rows re-decided, rows skipped);
     exact["counters_dev"], a device int64[2], is added to instead and never read here (no host
     synchronisation: for callers that look at the totals once at the end)."""
@@ -37,16 +42,37 @@ def topk_rows(A, k, discard, exact=None):
             assert A64.dtype == torch.float64 and tuple(A64.shape) == (n, nc) and A64.stride(1) == 1
             ex.mode, ex.A64, ex.lda64 = 1, A64.data_ptr(), A64.stride(0)
         else:
-            Gr, Gc = exact["G_rows"], exact["G_coh"]
-            assert Gr.shape[0] == n and Gc.shape[0] == nc and Gr.shape[1] == Gc.shape[1]
-            ex.mode, ex.G_rows, ex.G_coh = 2, Gr.data_ptr(), Gc.data_ptr()
-            ex.ldg, ex.K = Gr.stride(0), Gr.shape[1] - 2
-            ex.bnd_rows = exact["bnd_rows"].data_ptr()
+            Gc = exact["G_coh"]
+            assert Gc.shape[0] == nc
+            ex.G_coh, ex.ldg, ex.K = Gc.data_ptr(), Gc.stride(0), Gc.shape[1] - 2
+            bnd = exact["bnd_rows"]
+            assert bnd.dtype == torch.float32 and tuple(bnd.shape) == (n, 2) and bnd.is_contiguous()
+            ex.bnd_rows = bnd.data_ptr()
             ex.coh_gmax, ex.coh_qmax = float(exact["coh_gmax"]), float(exact["coh_qmax"])
             ex.err_coeff = float(exact.get("err_coeff", engine.ERR_COEFF))
+            if "rows64" in exact:
+                todo = torch.empty(max(n, 1), dtype=torch.int32, device=A.device)
+                todo_count = torch.zeros(1, dtype=torch.int32, device=A.device)
+                ex.mode, ex.todo, ex.todo_count = 3, todo.data_ptr(), todo_count.data_ptr()
+            else:
+                Gr = exact["G_rows"]
+                assert Gr.shape[0] == n and Gr.shape[1] == Gc.shape[1] and Gr.stride(0) == Gc.stride(0)
+                ex.mode, ex.G_rows = 2, Gr.data_ptr()
         ex_ptr = ctypes.byref(ex)
     _lib.check(lib.hypmi_topk_rows(engine._ptr(A), n, nc, A.stride(0), k, discard, engine._ptr(idx),
                                    ldi, ex_ptr, engine._ptr(ws), ws_bytes, engine.stream_ptr()))
+    if exact is not None and ex.mode == 3:
+        m = int(todo_count.item())  # rows that need exact values (waits for the selection above)
+        exact["redone"] = m
+        if m:
+            rows = torch.sort(todo[:m]).values
+            Gr, bnd_sub = exact["rows64"](rows)
+            assert Gr.shape[0] == m and Gr.shape[1] == Gc.shape[1] and Gr.stride(0) == Gc.stride(0)
+            assert bnd_sub.dtype == torch.float32 and tuple(bnd_sub.shape) == (m, 2) and bnd_sub.is_contiguous()
+            ex.mode, ex.G_rows, ex.bnd_rows, ex.row_map = 2, Gr.data_ptr(), bnd_sub.data_ptr(), rows.data_ptr()
+            ex.todo = ex.todo_count = None
+            _lib.check(lib.hypmi_topk_rows(engine._ptr(A), m, nc, A.stride(0), k, discard, engine._ptr(idx),
+                                           ldi, ctypes.byref(ex), engine._ptr(ws), ws_bytes, engine.stream_ptr()))
     if counters is not None:
         exact["counters"] = tuple(int(v) for v in counters.cpu())
     return idx

@@ -121,6 +121,12 @@ int hypmi_prologue(const hypmi_plan* plan, const float* x, int64_t n, int64_t ld
 int hypmi_prologue_pairs_supported(const hypmi_plan* plan);
 int hypmi_prologue_pairs(const hypmi_plan* plan, const float* x, int64_t n, int64_t ldx, int side, void* H,
                          void* H_other, float* G, void* workspace, int64_t workspace_bytes, void* stream);
+/* The same with one more optional result: bnd [n x 2] floats (|g|, |q|) of side `side` per row, the
+ * two terms a row contributes to the fp32 error bound of its scores (what hypmi_prologue_f64 returns
+ * as `bnd`, here from the fp32 rows) -- the input of hypmi_topk_rows mode 3. */
+int hypmi_prologue_pairs_bounds(const hypmi_plan* plan, const float* x, int64_t n, int64_t ldx, int side,
+                                void* H, void* H_other, float* G, float* bnd, void* workspace,
+                                int64_t workspace_bytes, void* stream);
 
 /* hypmi_prologue for callers that cannot allocate device memory or pass a workspace (code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc): the intermediate rows live
@@ -258,6 +264,15 @@ int hypmi_scatter_block(const float* blk, int64_t ldb, const int32_t* ri, int64_
  *   mode 2: entry (r, c) = <G_rows[r,:K], G_coh[c,:K]> + G_rows[r,K] + G_coh[c,K] from the fp64 packed
  *           rows of hypmi_prologue_f64; bnd_rows are that call's (|g|, |q|) pairs, coh_gmax / coh_qmax
  *           their maxima over the cohort, err_coeff the fp32 error coefficient (8 * 2^-24).
+ *   mode 3: the exact rows are not computed yet.  The call selects in fp32 as usual and appends to
+ *           `todo` (device int32, room for n_rows; *todo_count, device uint32, zeroed by the caller) every
+ *           row whose boundary has another entry inside its fp32 uncertainty band -- a few per cent of
+ *           the rows.  bnd_rows / coh_gmax / coh_qmax / err_coeff as in mode 2, except that the rows'
+ *           (|g|, |q|) may come from the fp32 prologue (hypmi_prologue_pairs_bounds).  The caller then
+ *           makes the fp64 packed rows of just those rows and calls again with mode 2 and
+ *           row_map = todo, n_rows = *todo_count: workgroup b re-selects row row_map[b] of A (and
+ *           overwrites its list) with exact values and bounds from row b of G_rows / bnd_rows.
+ *           Cohorts of up to 40 960 members.
  * counters (optional, device, 2 x uint64): rows with a re-decided boundary, rows skipped because more
  * than 64 entries tie with a boundary. */
 typedef struct {
@@ -271,6 +286,9 @@ typedef struct {
     const float* bnd_rows;
     float coh_gmax, coh_qmax, err_coeff;
     unsigned long long* counters;
+    const int32_t* row_map;
+    int32_t* todo;
+    uint32_t* todo_count;
 } hypmi_topk_exact;
 
 int64_t hypmi_topk_workspace_bytes(int64_t n_rows, int nc);

@@ -976,3 +976,54 @@ def test_backend_fused_and_separate_normalisation_agree():
     fused = be.score_snorm(xt, coh).cpu().numpy()
     be.fuse_apply = False
     assert np.array_equal(be.score_snorm(xt, coh).cpu().numpy(), fused)
+
+
+@pytest.mark.gpu
+def test_topk_lazy_exact_rows_equal_full_exact_rows():
+    """Top-k with float64 rows made only for the rows whose boundary is in doubt (two calls, a row map
+    in the second) selects what top-k with float64 rows for every row selects; near-ties are planted so
+    that a good part of the rows needs the second call."""
+    import torch
+
+    import synth
+    from hyperion_amd import engine
+    from hyperion_amd.engine import SIDE_ENROL, SIDE_TEST
+    from hyperion_amd.pdfs.plda import SPLDA
+    from hyperion_amd.score_norm.adapt_s_norm import lists_to_numpy, topk_rows
+    from hyperion_amd.transforms import LDA, CentWhiten, LNorm, TransformList
+
+    chain = synth.chain_cfg2(d=96, lda_dim=40, seed=3)
+    m = synth.make_splda(40, 12)
+    tl = TransformList([CentWhiten(mu=chain[0][1], T=chain[0][2], name="cw"), LNorm(name="ln"),
+                        LDA(mu=chain[2][1], T=chain[2][2], name="lda")])
+    plan = SPLDA(mu=m["mu"], V=m["V"], W=m["W"]).score_plan(tl)
+    assert plan.pairs_in_prologue()
+    xr, _ = synth.raw_xvectors(700, d=96, seed=31, num_centers=40)
+    xc, _ = synth.raw_xvectors(3000, d=96, seed=32, num_centers=300)
+    xc[2700:] = xc[:300] * (1.0 + 3e-8 * np.random.RandomState(5).randn(300, 1))  # near-duplicates: near-ties
+    k = 60
+    xr_d, xc_d = engine.upload(xr), engine.upload(xc)
+    Gr, bnd32 = plan.prologue_split(xr_d, SIDE_ENROL, bounds=True)
+    A = engine.score(Gr, plan.prologue_split(xc_d, SIDE_TEST))
+    Gc64, bc = plan.prologue_f64(engine.upload64(xc), SIDE_TEST)
+    Gr64, br = plan.prologue_f64(engine.upload64(xr), SIDE_ENROL)
+    assert torch.allclose(bnd32, br, rtol=1e-5, atol=1e-6)
+    common = {"G_coh": Gc64, "coh_gmax": float(bc[:, 0].max()), "coh_qmax": float(bc[:, 1].max())}
+    full = dict(common, G_rows=Gr64, bnd_rows=br, count=True)
+    ref = np.sort(lists_to_numpy(topk_rows(A, k, 3, full), k), axis=1)
+    asked = []
+
+    def rows64(rows):
+        asked.append(rows.cpu().numpy())
+        return plan.prologue_f64(engine.upload64(xr[rows.cpu().numpy()]), SIDE_ENROL)
+
+    lazy = dict(common, bnd_rows=bnd32, rows64=rows64, count=True)
+    got = np.sort(lists_to_numpy(topk_rows(A, k, 3, lazy), k), axis=1)
+    assert np.array_equal(got, ref)
+    assert lazy["counters"] == full["counters"] and full["counters"][0] > 20
+    assert len(asked) == 1 and lazy["redone"] == len(asked[0]) and 20 < lazy["redone"] < 350
+    assert np.all(np.diff(asked[0]) > 0)
+    # and the float64 oracle's own selection
+    S64 = (Gr64[:, :-2] @ Gc64[:, :-2].T + Gr64[:, -2:-1] + Gc64[:, -2][None, :]).cpu().numpy()
+    order = np.argsort(-S64, axis=1, kind="stable")[:, 3:3 + k]
+    assert np.array_equal(np.sort(order, axis=1), got)
