@@ -22,7 +22,7 @@ from collections import defaultdict
 
 def find(d, pat):
     r = glob.glob(os.path.join(d, "**", pat), recursive=True)
-    return r[0] if r else None
+    return max(r, key=os.path.getmtime) if r else None  # the latest run, if the directory holds several
 
 
 def main(d, out, traffic=None, roof=None):
@@ -50,11 +50,16 @@ def main(d, out, traffic=None, roof=None):
         for k, cs in acc.items():
             for c, v in cs.items():
                 lines.append("%-70s %-28s n=%-4d mean=%.6g" % (k[:70], c, len(v), sum(v) / len(v)))
-                means[(k, c)] = sum(v) / len(v)
+                means[(k, c)] = (sum(v), len(v))
     if traffic:
         workload, sub, path = traffic
-        fetch = [v for (k, c), v in means.items() if sub in k and c == "FETCH_SIZE"]
-        write = [v for (k, c), v in means.items() if sub in k and c == "WRITE_SIZE"]
+        # every kernel whose name holds the substring (template variants of one kernel): mean over all
+        # their dispatches
+        def mean_of(counter):
+            hit = [v for (k, c), v in means.items() if sub in k and c == counter]
+            return [sum(t for t, _ in hit) / sum(n for _, n in hit)] if hit else []
+
+        fetch, write = mean_of("FETCH_SIZE"), mean_of("WRITE_SIZE")
         if fetch and write:
             try:
                 with open(path) as f:
@@ -74,11 +79,12 @@ def main(d, out, traffic=None, roof=None):
         work, peak = float(roof[0]), float(roof[1])
         hit = [r for r in rows if traffic[1] in r["Name"]]
         if hit:
-            avg_s = float(hit[0]["AverageNs"]) * 1e-9
+            calls = sum(int(r["Calls"]) for r in hit)
+            avg_s = sum(float(r["TotalDurationNs"]) for r in hit) / calls * 1e-9
             lines.append("")
-            lines.append("roofline of %s from this trace: %.6g algorithmic units per launch / %.4f ms average "
-                         "over %s launches = %.6g per s = %.4f of the peak %.6g"
-                         % (traffic[1], work, avg_s * 1e3, hit[0]["Calls"], work / avg_s, work / avg_s / peak, peak))
+            lines.append("roofline of %s (%d kernel variant(s)) from this trace: %.6g algorithmic units per launch / "
+                         "%.4f ms average over %d launches = %.6g per s = %.4f of the peak %.6g"
+                         % (traffic[1], len(hit), work, avg_s * 1e3, calls, work / avg_s, work / avg_s / peak, peak))
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
