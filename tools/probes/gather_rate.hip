@@ -216,6 +216,70 @@ __global__ __launch_bounds__(GS) void gather2(const float* __restrict__ X, int64
     }
 }
 
+// As gather2 (both moments) with list entries stored as 32-bit LDS byte offsets (four per 16-byte load):
+// no address instruction, twice the index bytes.
+template <int D>
+__global__ __launch_bounds__(GS) void gather3(const float* __restrict__ X, int64_t ldx, int nc,
+                                              const uint32_t* __restrict__ idx4, int64_t ldi, int k, int64_t Q,
+                                              float* __restrict__ mean, float* __restrict__ istd, int64_t ldo) {
+    extern __shared__ __attribute__((aligned(16))) float xr[];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 2;
+    const float rp0 = X[r0 * ldx], rp1 = X[(r0 + 1) * ldx];
+    for (int c = tid; c < nc; c += GS) {
+        xr[c * 2] = X[r0 * ldx + c] - rp0;
+        xr[c * 2 + 1] = X[(r0 + 1) * ldx + c] - rp1;
+    }
+    __syncthreads();
+    const char* xb = reinterpret_cast<const char*>(xr);
+    const int G = k >> 2;
+    const int n = (int)(Q / GS) * G;
+    const uint4* p = reinterpret_cast<const uint4*>(idx4) + tid;
+    const int64_t wrap = (int64_t)GS - (int64_t)G * ldi;
+    int g_ld = 0;
+    uint4 ring[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        ring[d] = *p;
+        p += ldi;
+        if (++g_ld == G) { g_ld = 0; p += wrap; }
+    }
+    float s1a = 0.f, s1b = 0.f, s2a = 0.f, s2b = 0.f;
+    int g = 0;
+    int64_t q = tid;
+    auto add = [&](unsigned addr) {
+        const float2 v = *reinterpret_cast<const float2*>(xb + addr);
+        asm("v_add_f32 %0, %1, %0" : "+v"(s1a) : "v"(v.x));
+        asm("v_add_f32 %0, %1, %0" : "+v"(s1b) : "v"(v.y));
+        asm("v_fma_f32 %0, %1, %1, %0" : "+v"(s2a) : "v"(v.x));
+        asm("v_fma_f32 %0, %1, %1, %0" : "+v"(s2b) : "v"(v.y));
+    };
+    for (int i = 0; i < n; i += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (i + d < n) {
+                const uint4 pk = ring[d];
+                if (i + d + D < n) {
+                    ring[d] = *p;
+                    p += ldi;
+                    if (++g_ld == G) { g_ld = 0; p += wrap; }
+                }
+                add(pk.x); add(pk.y); add(pk.z); add(pk.w);
+                if (++g == G) {
+                    const float m0 = s1a / k, m1 = s1b / k;
+                    mean[r0 * ldo + q] = m0 + rp0;
+                    mean[(r0 + 1) * ldo + q] = m1 + rp1;
+                    istd[r0 * ldo + q] = rsqrtf(fmaxf(s2a / k - m0 * m0, 1e-10f));
+                    istd[(r0 + 1) * ldo + q] = rsqrtf(fmaxf(s2b / k - m1 * m1, 1e-10f));
+                    s1a = s1b = s2a = s2b = 0.f;
+                    g = 0;
+                    q += GS;
+                }
+            }
+        }
+    }
+}
+
 static uint64_t rng_state = 88172645463325252ull;
 static inline uint32_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 11); }
 
@@ -335,6 +399,37 @@ int main(int argc, char** argv) {
         printf("pattern: %s (%d rows x %lld lists x %d)\n", pats[pat], rows, (long long)Q, k);
         GATHER(0)
         GATHER2(4, 0, 0) GATHER2(8, 0, 0) GATHER2(8, 1, 0) GATHER2(8, 2, 0)
+        {   // 32-bit byte-offset lists
+            std::vector<uint32_t> h4((size_t)(k / 4) * Q * 4);
+            for (int64_t q = 0; q < Q; ++q)
+                for (int j = 0; j < k; ++j)
+                    h4[((size_t)(j >> 2) * ldi + q) * 4 + (j & 3)] = 8u * hi[((size_t)(j >> 3) * ldi + q) * 8 + (j & 7)];
+            uint32_t* idx4;
+            CK(hipMalloc(&idx4, h4.size() * 4));
+            CK(hipMemcpy(idx4, h4.data(), h4.size() * 4, hipMemcpyHostToDevice));
+#define GATHER3(D)                                                                                             \
+    {                                                                                                          \
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gather3<D>),                                     \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, nc * 8));                           \
+        float best = 1e9f;                                                                                     \
+        for (int rep = 0; rep < 3; ++rep) {                                                                    \
+            CK(hipEventRecord(e0));                                                                            \
+            hipLaunchKernelGGL((gather3<D>), dim3(rows / 2), dim3(GS), nc * 8, 0, X, ldx, nc, idx4, ldi, k, Q, \
+                               mean, istd, ldo);                                                               \
+            CK(hipEventRecord(e1));                                                                            \
+            CK(hipEventSynchronize(e1));                                                                       \
+            float ms;                                                                                          \
+            CK(hipEventElapsedTime(&ms, e0, e1));                                                              \
+            if (ms < best) best = ms;                                                                          \
+        }                                                                                                      \
+        CK(hipGetLastError());                                                                                 \
+        const double el = (double)rows * Q * k;                                                                \
+        printf("  32-bit offsets, ring D=%d  %8.3f ms  %5.2f clk per wave-entry per CU\n", D, best,             \
+               128.0 * ncu * ghz * 1e9 * best * 1e-3 / el);                                                    \
+    }
+            GATHER3(4) GATHER3(8)
+            CK(hipFree(idx4));
+        }
     }
     return 0;
 }
