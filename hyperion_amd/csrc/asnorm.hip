@@ -1146,26 +1146,33 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
     const int n = nl * G;  // the launcher keeps this below 2^31
     const uint4* base = reinterpret_cast<const uint4*>(idx8);
     // A lane without a list in the last round walks the block's last list and stores nothing.
-    // The index loads of a lane form one stream over (list, group); its pointer moves by ldi inside
-    // a list and by `hop` (plus `hop_fix` into the last round) from the end of one list to the next.
-    const int64_t q_first = q0 + tid < q1 ? q0 + tid : q1 - 1;
-    const int64_t q_last_want = q0 + tid + (int64_t)(nl - 1) * GS_THREADS;
-    const int64_t hop = (int64_t)GS_THREADS - (int64_t)(G - 1) * ldi;
-    const int64_t hop_fix = (nl >= 2 && q_last_want >= q1) ? (q1 - 1) - q_last_want : 0;  // <= 0
-    const uint4* p_ld = base + q_first;
+    // The index loads of a lane form one stream over (list, group).  Its address is a uniform part --
+    // group g of the lists of round l starts at idx8 + (g ldi + q0 + 1024 l) 16 bytes, stepped with
+    // scalar instructions -- plus 16 bytes per lane, so the loads go through a buffer descriptor
+    // (scalar base, per-lane offset) and the stream costs no vector instruction besides the load.
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const char* sp = reinterpret_cast<const char*>(idx8) + q0 * 16;  // uniform
+    const int64_t step_b = ldi * 16, hop_b = ((int64_t)GS_THREADS - (int64_t)(G - 1) * ldi) * 16;
+    const int64_t last_lists = (q1 - q0) - (int64_t)(nl - 1) * GS_THREADS;  // lists of the last round, 1..1024
+    const unsigned voff_last = (unsigned)(tid < last_lists ? tid : last_lists - 1) * 16u;
+    unsigned voff = nl == 1 ? voff_last : (unsigned)tid * 16u;
     int l_ld = 0, g_ld = 0;  // uniform
     uint4 ring[GP_RING];
-#define HYPMI_NEXT_LOAD(dst)                                         \
-    {                                                                \
-        dst = *p_ld;                                                 \
-        if (++g_ld == G) {                                           \
-            g_ld = 0;                                                \
-            ++l_ld;                                                  \
-            p_ld += hop;                                             \
-            if (l_ld == nl - 1) p_ld += hop_fix;                     \
-        } else {                                                     \
-            p_ld += ldi;                                             \
-        }                                                            \
+#define HYPMI_NEXT_LOAD(dst)                                                                              \
+    {                                                                                                     \
+        const v4u w_ = __builtin_amdgcn_raw_buffer_load_b128(                                             \
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sp), 0, 16 * GS_THREADS, 0x00020000), voff, 0, 0); \
+        dst = make_uint4(w_[0], w_[1], w_[2], w_[3]);                                                     \
+        if (++g_ld < G) {                                                                                 \
+            sp += step_b;                                                                                 \
+        } else if (l_ld + 1 < nl) {                                                                       \
+            g_ld = 0;                                                                                     \
+            ++l_ld;                                                                                       \
+            sp += hop_b;                                                                                  \
+            if (l_ld == nl - 1) voff = voff_last;                                                         \
+        } else {                                                                                          \
+            g_ld = G - 1; /* the stream is over: further loads re-read its last group */                  \
+        }                                                                                                 \
     }
     // APPLY: what the end of a list needs from global memory -- the raw scores of the R rows and the R
     // transposed statistics (one 4 R-byte load each) -- is requested when the list begins, so that the
@@ -1186,92 +1193,100 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
     }
     HYPMI_APPLY_PREFETCH(0)
 #pragma unroll
-    for (int d = 0; d < GP_RING; ++d)
-        if (d < n) HYPMI_NEXT_LOAD(ring[d])
+    for (int d = 0; d < GP_RING; ++d) HYPMI_NEXT_LOAD(ring[d])
 
     float s1[R], s2[R];
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) s1[rr] = s2[rr] = 0.f;
     int g = 0, l = 0;
     const float inv_k = 1.0f / (float)k, floor2 = floor_ * floor_, inv_floor = 1.0f / floor_;
-    for (int i = 0; i < n; i += GP_RING) {
-#pragma unroll
-        for (int d = 0; d < GP_RING; ++d) {
-            if (i + d < n) {
-                uint4 pk = ring[d];
-                if (i + d + GP_RING < n) HYPMI_NEXT_LOAD(ring[d])
-                if (krem != 0 && g == G - 1) {
-                    pk.x = (pk.x & keep[0]) | fill[0];
-                    pk.y = (pk.y & keep[1]) | fill[1];
-                    pk.z = (pk.z & keep[2]) | fill[2];
-                    pk.w = (pk.w & keep[3]) | fill[3];
-                }
-                // addresses, then all eight reads, then the arithmetic (the fences keep the reads of a
-                // group in flight together instead of one wait per read)
-                unsigned a[8];
-                a[0] = entry_addr<R, 0>(pk.x, xbase); a[1] = entry_addr<R, 1>(pk.x, xbase);
-                a[2] = entry_addr<R, 0>(pk.y, xbase); a[3] = entry_addr<R, 1>(pk.y, xbase);
-                a[4] = entry_addr<R, 0>(pk.z, xbase); a[5] = entry_addr<R, 1>(pk.z, xbase);
-                a[6] = entry_addr<R, 0>(pk.w, xbase); a[7] = entry_addr<R, 1>(pk.w, xbase);
-                __builtin_amdgcn_sched_barrier(0);
-                typename LdsVec<R>::type val[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) val[e] = lds_vec<R>(a[e]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-#pragma unroll
-                    for (int rr = 0; rr < R; ++rr) moment_step(s1[rr], s2[rr], lds_vec_elem<R>(val[e], rr));
-                if (++g == G) {
-                    // The sums carry fp32 rounding (about 1e-6 relative); so does this arithmetic.
-                    const int64_t q = q0 + tid + (int64_t)l * GS_THREADS;
-                    const bool live_q = q < q1;
-                    float lp[R];
-                    bool redo = false;
-#pragma unroll
-                    for (int rr = 0; rr < R; ++rr) {
-                        lp[rr] = 0.f;
-                        const float md = s1[rr] * inv_k, ms = s2[rr] * inv_k;
-                        redo |= fmaf(-md, md, ms) * GP_AMP < ms;  // false for NaN: those stay NaN
-                    }
-                    if (redo && live_q) {
-                        const ShiftedMoments<R> m = list_moments_shifted<R>(xb, base + q, ldi, k);
-#pragma unroll
-                        for (int rr = 0; rr < R; ++rr) {
-                            lp[rr] = m.piv[rr];
-                            s1[rr] = m.s1[rr];
-                            s2[rr] = m.s2[rr];
-                        }
-                        atomicAdd(&g_gather_redo, 1ull);
-                    }
-#pragma unroll
-                    for (int rr = 0; rr < R; ++rr) {
-                        const float md = s1[rr] * inv_k;
-                        float var = fmaf(-md, md, s2[rr] * inv_k);
-                        var = var > 0.f ? var : (var == var ? 0.f : var);  // NaN stays NaN
-                        // 1 / max(sqrt(var), floor): v_rsq_f32 is good to one unit in the last place
-                        const float is = var < floor2 ? inv_floor : __builtin_amdgcn_rsqf(var);
-                        if (live_q && r0 + rr < n_rows) {
-                            const float m = (rowpiv[rr] + lp[rr]) + md;
-                            if (APPLY) {
-                                ap.out[(r0 + rr) * ap.ldo + q] = asnorm_value(
-                                    ps[rr], m, is, lds_vec_elem<R>(pm, rr), lds_vec_elem<R>(pi, rr));
-                            } else {
-                                mean[(r0 + rr) * ldo + q] = m;
-                                istd[(r0 + rr) * ldo + q] = is;
-                            }
-                        }
-                        s1[rr] = s2[rr] = 0.f;
-                    }
-                    g = 0;
-                    ++l;
-                    if (l < nl) HYPMI_APPLY_PREFETCH(l)
-                }
-            }
-        }
+    // One group of eight entries from ring slot D: addresses, then all eight reads, then the arithmetic
+    // (the fences keep the reads of a group in flight together instead of one wait per read).  The
+    // slot is reloaded (RELOAD) once its contents have become addresses, so that the new group can take
+    // the registers of the old one; in the main loop every slot is reloaded unconditionally, which
+    // lets the compiler count the loads in flight instead of waiting for all of them.
+#define HYPMI_GROUP(D, RELOAD)                                                                                  \
+    {                                                                                                           \
+        unsigned a[8];                                                                                          \
+        if (krem != 0 && g == G - 1) {                                                                          \
+            const unsigned w0 = (ring[D].x & keep[0]) | fill[0], w1 = (ring[D].y & keep[1]) | fill[1],          \
+                           w2 = (ring[D].z & keep[2]) | fill[2], w3 = (ring[D].w & keep[3]) | fill[3];          \
+            a[0] = entry_addr<R, 0>(w0, xbase); a[1] = entry_addr<R, 1>(w0, xbase);                             \
+            a[2] = entry_addr<R, 0>(w1, xbase); a[3] = entry_addr<R, 1>(w1, xbase);                             \
+            a[4] = entry_addr<R, 0>(w2, xbase); a[5] = entry_addr<R, 1>(w2, xbase);                             \
+            a[6] = entry_addr<R, 0>(w3, xbase); a[7] = entry_addr<R, 1>(w3, xbase);                             \
+        } else {                                                                                                \
+            a[0] = entry_addr<R, 0>(ring[D].x, xbase); a[1] = entry_addr<R, 1>(ring[D].x, xbase);               \
+            a[2] = entry_addr<R, 0>(ring[D].y, xbase); a[3] = entry_addr<R, 1>(ring[D].y, xbase);               \
+            a[4] = entry_addr<R, 0>(ring[D].z, xbase); a[5] = entry_addr<R, 1>(ring[D].z, xbase);               \
+            a[6] = entry_addr<R, 0>(ring[D].w, xbase); a[7] = entry_addr<R, 1>(ring[D].w, xbase);               \
+        }                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        if (RELOAD) HYPMI_NEXT_LOAD(ring[D])                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        typename LdsVec<R>::type val[8];                                                                        \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) val[e] = lds_vec<R>(a[e]);                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                           \
+            _Pragma("unroll") for (int rr = 0; rr < R; ++rr)                                                    \
+                moment_step(s1[rr], s2[rr], lds_vec_elem<R>(val[e], rr));                                       \
+        if (++g == G) {                                                                                         \
+            /* The sums carry fp32 rounding (about 1e-6 relative); so does this arithmetic. */                  \
+            const int64_t q = q0 + tid + (int64_t)l * GS_THREADS;                                               \
+            const bool live_q = q < q1;                                                                         \
+            float lp[R];                                                                                        \
+            bool redo = false;                                                                                  \
+            _Pragma("unroll") for (int rr = 0; rr < R; ++rr) {                                                  \
+                lp[rr] = 0.f;                                                                                   \
+                const float md = s1[rr] * inv_k, ms = s2[rr] * inv_k;                                           \
+                redo |= fmaf(-md, md, ms) * GP_AMP < ms; /* false for NaN: those stay NaN */                    \
+            }                                                                                                   \
+            if (redo && live_q) {                                                                               \
+                const ShiftedMoments<R> m = list_moments_shifted<R>(xb, base + q, ldi, k);                      \
+                _Pragma("unroll") for (int rr = 0; rr < R; ++rr) {                                              \
+                    lp[rr] = m.piv[rr];                                                                         \
+                    s1[rr] = m.s1[rr];                                                                          \
+                    s2[rr] = m.s2[rr];                                                                          \
+                }                                                                                               \
+                atomicAdd(&g_gather_redo, 1ull);                                                                \
+            }                                                                                                   \
+            _Pragma("unroll") for (int rr = 0; rr < R; ++rr) {                                                  \
+                const float md = s1[rr] * inv_k;                                                                \
+                float var = fmaf(-md, md, s2[rr] * inv_k);                                                      \
+                var = var > 0.f ? var : (var == var ? 0.f : var); /* NaN stays NaN */                           \
+                /* 1 / max(sqrt(var), floor): v_rsq_f32 is good to one unit in the last place */                \
+                const float is = var < floor2 ? inv_floor : __builtin_amdgcn_rsqf(var);                         \
+                if (live_q && r0 + rr < n_rows) {                                                               \
+                    const float m = (rowpiv[rr] + lp[rr]) + md;                                                 \
+                    if (APPLY) {                                                                                \
+                        ap.out[(r0 + rr) * ap.ldo + q] =                                                        \
+                            asnorm_value(ps[rr], m, is, lds_vec_elem<R>(pm, rr), lds_vec_elem<R>(pi, rr));      \
+                    } else {                                                                                    \
+                        mean[(r0 + rr) * ldo + q] = m;                                                          \
+                        istd[(r0 + rr) * ldo + q] = is;                                                         \
+                    }                                                                                           \
+                }                                                                                               \
+                s1[rr] = s2[rr] = 0.f;                                                                          \
+            }                                                                                                   \
+            g = 0;                                                                                              \
+            ++l;                                                                                                \
+            if (l < nl) HYPMI_APPLY_PREFETCH(l)                                                                 \
+        }                                                                                                       \
     }
+    static_assert(GP_RING == 4, "the walk below names the four ring slots");
+    int i = 0;
+    for (; i + GP_RING <= n; i += GP_RING) {
+        HYPMI_GROUP(0, true)
+        HYPMI_GROUP(1, true)
+        HYPMI_GROUP(2, true)
+        HYPMI_GROUP(3, true)
+    }
+    if (i < n) HYPMI_GROUP(0, false)
+    if (i + 1 < n) HYPMI_GROUP(1, false)
+    if (i + 2 < n) HYPMI_GROUP(2, false)
 }
 
+#undef HYPMI_GROUP
 #undef HYPMI_NEXT_LOAD
 #undef HYPMI_APPLY_PREFETCH
 
