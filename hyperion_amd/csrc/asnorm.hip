@@ -975,6 +975,7 @@ __global__ __launch_bounds__(GS_THREADS) void gather_stats_kernel(
 // the few (row, list) pairs beyond that (a selection far out in the tail of its row, or constant)
 // the lane walks the list again around the list's own first member, which is what the general kernel
 // above does for every pair.
+constexpr int MAX_LDS_BYTES = 160 * 1024;  // LDS of a CU: what one workgroup of the gather kernels may take
 constexpr int GP_RING = 4;
 constexpr float GP_AMP = 16.f;
 constexpr int GP_XCD_GROUPS = 16;  // row groups that share 128-byte lines of the transposed T-part statistics
@@ -1095,9 +1096,67 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
         if (grp * R >= n_rows) return;
     }
     const int64_t r0 = grp * R;
+    // The rows come in with 16-byte loads that are all issued before anything waits for them (one row
+    // of 20 000 floats is five loads per lane; fetched one float at a time, each behind its own wait,
+    // the fill took a quarter of the time of a workgroup that walks ten lists per lane).
     // pivot of a row: mean of its first min(nc, 1024) entries (the cohort order carries no meaning)
     float rowpiv[R];
-    {
+    const bool vec_ok = ldx % 4 == 0 && reinterpret_cast<uintptr_t>(X) % 16 == 0 && nc >= 4;  // uniform
+    if (vec_ok) {
+        // float4 pieces per lane and row for the largest cohort that fits LDS with R rows
+        constexpr int FILL = ((MAX_LDS_BYTES / 4 - GP_SCRATCH_FLOATS) / R / 4 + GS_THREADS - 1) / GS_THREADS;
+        const int nc4 = nc >> 2, rem = nc & 3;
+        typedef typename LdsVec<4>::type f4;
+        f4 v[FILL][R];
+        float tail[R];
+#pragma unroll
+        for (int it = 0; it < FILL; ++it) {
+            const int c4 = tid + it * GS_THREADS;
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                v[it][rr] = f4{0.f, 0.f, 0.f, 0.f};
+                if (c4 < nc4 && r0 + rr < n_rows)
+                    v[it][rr] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(X + (r0 + rr) * ldx) + c4);
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr)
+            tail[rr] = (tid < rem && r0 + rr < n_rows) ? X[(r0 + rr) * ldx + 4 * nc4 + tid] : 0.f;
+        const int ns4 = nc4 < GS_THREADS / 4 ? nc4 : GS_THREADS / 4;  // the first 4 ns4 entries make the pivot
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            float p = tid < ns4 ? (v[0][rr].x + v[0][rr].y) + (v[0][rr].z + v[0][rr].w) : 0.f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
+            if (lane == 0) red[rr * 16 + wave] = p;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < GS_THREADS / 64; ++w) sum += red[rr * 16 + w];
+            rowpiv[rr] = sum / (float)(4 * ns4);
+        }
+#pragma unroll
+        for (int it = 0; it < FILL; ++it) {
+            const int c4 = tid + it * GS_THREADS;
+            if (c4 < nc4) {
+                float* dst = xr + (size_t)c4 * 4 * R;
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                    dst[0 * R + rr] = v[it][rr].x - rowpiv[rr];
+                    dst[1 * R + rr] = v[it][rr].y - rowpiv[rr];
+                    dst[2 * R + rr] = v[it][rr].z - rowpiv[rr];
+                    dst[3 * R + rr] = v[it][rr].w - rowpiv[rr];
+                }
+            }
+        }
+        if (tid < rem) {
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) xr[(size_t)(4 * nc4 + tid) * R + rr] = tail[rr] - rowpiv[rr];
+        }
+    } else {
         const int ns = nc < GS_THREADS ? nc : GS_THREADS;
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
@@ -1109,18 +1168,18 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
         __syncthreads();
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
-            float s = 0.f;
+            float sum = 0.f;
 #pragma unroll
-            for (int w = 0; w < GS_THREADS / 64; ++w) s += red[rr * 16 + w];
-            rowpiv[rr] = s / (float)ns;
+            for (int w = 0; w < GS_THREADS / 64; ++w) sum += red[rr * 16 + w];
+            rowpiv[rr] = sum / (float)ns;
         }
-    }
 #pragma unroll
-    for (int rr = 0; rr < R; ++rr) {
-        const bool live = r0 + rr < n_rows;
-        const float* src = X + (r0 + rr) * ldx;
-        for (int c = tid; c < nc; c += GS_THREADS)
-            xr[c * R + rr] = live ? __builtin_nontemporal_load(src + c) - rowpiv[rr] : 0.f;
+        for (int rr = 0; rr < R; ++rr) {
+            const bool live = r0 + rr < n_rows;
+            const float* src = X + (r0 + rr) * ldx;
+            for (int c = tid; c < nc; c += GS_THREADS)
+                xr[c * R + rr] = live ? __builtin_nontemporal_load(src + c) - rowpiv[rr] : 0.f;
+        }
     }
     __syncthreads();
     const char* xb = reinterpret_cast<const char*>(xr);
@@ -1411,8 +1470,6 @@ __global__ __launch_bounds__(256) void mask_zero_kernel(float* __restrict__ X, i
     const int64_t i = blockIdx.y;
     if (i < rows && j < cols && mask[i * ldm + j] == 0) X[i * ldx + j] = 0.f;
 }
-
-constexpr int MAX_LDS_BYTES = 160 * 1024;
 
 }  // namespace
 
