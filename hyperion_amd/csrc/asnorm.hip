@@ -406,7 +406,10 @@ struct TopkRegs {
             const unsigned bracket_lo = prefix;
             if (tid == 0) sh.ncand = 0;
             __syncthreads();
-            auto inside = [prefix, width](unsigned kx) { return kx != 0 && kx - prefix < width; };  // key 0 = no element
+            // one compare per key: the bracket is aligned, so key 0 ("no element") falls outside it unless
+            // it starts at 0, in which case it starts at 1 instead
+            const unsigned first_key = prefix == 0 ? 1u : prefix, span = width - (first_key - prefix);
+            auto inside = [first_key, span](unsigned kx) { return kx - first_key < span; };
             const unsigned mine = wave_count(inside);
             unsigned at = 0;
             if (lane == 0) at = atomicAdd(&sh.ncand, mine);  // one slot range per wave
