@@ -930,7 +930,7 @@ def test_gather_stats_tail_selection_and_constant_members():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("ne,nt,nc,k", [(37, 1500, 600, 50), (130, 70, 20_440, 300), (3, 2100, 30_000, 40),
-                                        (260, 1030, 4_000, 9)])
+                                        (260, 1030, 4_000, 9), (6, 20_000, 600, 50)])  # last: lists split over blocks
 def test_gather_apply_equals_gather_then_apply(ne, nt, nc, k):
     """The Z-part statistics kernel that finishes the normalisation itself gives the bits of the two
     separate launches, for every rows-per-workgroup variant and ragged shapes (row groups are
