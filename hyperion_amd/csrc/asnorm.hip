@@ -1084,6 +1084,17 @@ __device__ __noinline__ ShiftedMoments<R> list_moments_shifted(const char* xb, c
 // neighbouring rows need at about the same time, so the row groups are numbered such that
 // GP_XCD_GROUPS consecutive ones run on the same XCD (workgroups go to the XCDs round-robin) and
 // share those lines in its L2.  The loads ride in the shadow of the walk, which leaves HBM idle.
+// Issue priority of the calling wave: level (turn mod 4).  The four waves of a SIMD take turns at every
+// level, so that none of them is served first for its whole life.
+__device__ __forceinline__ void rotate_priority(int turn) {
+    switch (turn & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+
 template <int R, bool APPLY>
 __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
     const float* __restrict__ X, int64_t ldx, int64_t n_rows, int nc, const uint16_t* __restrict__ idx8,
@@ -1332,10 +1343,12 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
             }                                                                                                   \
             g = 0;                                                                                              \
             ++l;                                                                                                \
+            rotate_priority((wave >> 2) + l);                                                                   \
             if (l < nl) HYPMI_APPLY_PREFETCH(l)                                                                 \
         }                                                                                                       \
     }
     static_assert(GP_RING == 4, "the walk below names the four ring slots");
+    rotate_priority(wave >> 2);
     int i = 0;
     for (; i + GP_RING <= n; i += GP_RING) {
         HYPMI_GROUP(0, true)
