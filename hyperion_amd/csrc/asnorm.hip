@@ -1214,8 +1214,12 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
         keep[w] = (lo_ok ? 0xffffu : 0u) | (hi_ok ? 0xffff0000u : 0u);
         fill[w] = (lo_ok ? 0u : (unsigned)nc) | (hi_ok ? 0u : (unsigned)nc << 16);
     }
-    // lists per lane (the last may be missing) and index groups per lane: the same in every lane
-    const int nl = __builtin_amdgcn_readfirstlane((int)((q1 - q0 + GS_THREADS - 1) / GS_THREADS));
+    // lists per lane (the last may be missing) and index groups per lane: the same in every lane of a
+    // wave.  A wave none of whose lanes has a list in the block's last round leaves that round out.
+    const int nl_all = __builtin_amdgcn_readfirstlane((int)((q1 - q0 + GS_THREADS - 1) / GS_THREADS));
+    const int64_t wave_first_last = (int64_t)(nl_all - 1) * GS_THREADS + 64 * __builtin_amdgcn_readfirstlane(wave);
+    const int nl = nl_all - (wave_first_last >= q1 - q0 ? 1 : 0);
+    if (nl == 0) return;  // (no barrier follows)
     const int n = nl * G;  // the launcher keeps this below 2^31
     const uint4* base = reinterpret_cast<const uint4*>(idx8);
     // A lane without a list in the last round walks the block's last list and stores nothing.
@@ -1226,9 +1230,9 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     const char* sp = reinterpret_cast<const char*>(idx8) + q0 * 16;  // uniform
     const int64_t step_b = ldi * 16, hop_b = ((int64_t)GS_THREADS - (int64_t)(G - 1) * ldi) * 16;
-    const int64_t last_lists = (q1 - q0) - (int64_t)(nl - 1) * GS_THREADS;  // lists of the last round, 1..1024
+    const int64_t last_lists = (q1 - q0) - (int64_t)(nl_all - 1) * GS_THREADS;  // lists of the last round, 1..1024
     const unsigned voff_last = (unsigned)(tid < last_lists ? tid : last_lists - 1) * 16u;
-    unsigned voff = nl == 1 ? voff_last : (unsigned)tid * 16u;
+    unsigned voff = nl_all == 1 ? voff_last : (unsigned)tid * 16u;
     int l_ld = 0, g_ld = 0;  // uniform
     uint4 ring[GP_RING];
 #define HYPMI_NEXT_LOAD(dst)                                                                              \
@@ -1242,7 +1246,7 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
             g_ld = 0;                                                                                     \
             ++l_ld;                                                                                       \
             sp += hop_b;                                                                                  \
-            if (l_ld == nl - 1) voff = voff_last;                                                         \
+            if (l_ld == nl_all - 1) voff = voff_last;                                                     \
         } else {                                                                                          \
             g_ld = G - 1; /* the stream is over: further loads re-read its last group */                  \
         }                                                                                                 \
