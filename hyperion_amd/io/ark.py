@@ -4,8 +4,8 @@
 Reading the x-vectors of a trial list is the step in front of the scoring path: vectors asked for
 with squeeze=True go through hypmi_ark_read_vectors (threaded pread straight into one buffer,
 page-locked when a HIP device is present, so that the device copy is a single transfer).  Matrices,
-row ranges and un-squeezed reads are parsed record by record on the host.  Compressed and text
-archives are not supported."""
+row ranges and un-squeezed reads are parsed record by record on the host; compressed matrices (feature
+archives) are decoded and encoded by kaldi_compressed.py.  Text archives are not supported."""
 import ctypes
 import os
 import struct
@@ -14,6 +14,7 @@ import numpy as np
 
 from .. import _lib
 from ..hyp_defs import float_cpu, float_save
+from . import kaldi_compressed
 from ..utils.scp_list import SCPList
 
 _MARK = b"\0B"
@@ -35,15 +36,17 @@ def _combine_ranges(read_range, row_offset, num_rows):
 
 
 def _read_header(f):
-    """(dtype, is_matrix, rows, cols) of the record at the file position
-    (kaldi_matrix.py:63-105, 196-230)."""
-    head = f.read(5)
-    if head[:2] != _MARK:
+    """(dtype, is_matrix, rows, cols) of the plain record at the file position, or
+    ("compressed", format) with the position behind the token of a compressed matrix
+    (kaldi_matrix.py:63-105, 196-230, 714-727)."""
+    if f.read(2) != _MARK:
         raise ValueError("not a binary Kaldi record (text archives are not supported)")
-    token = head[2:5]
+    token = kaldi_compressed.read_token(f)
     if token[:1] == b"C":
-        raise ValueError("compressed Kaldi matrices are not supported")
-    if token[:1] not in (b"F", b"D") or token[1:2] not in (b"V", b"M") or token[2:3] != b" ":
+        if token not in kaldi_compressed.TOKENS:
+            raise ValueError("Unexpected token %s" % token.decode("ascii", "replace"))
+        return "compressed", kaldi_compressed.TOKENS[token]
+    if len(token) != 2 or token[:1] not in (b"F", b"D") or token[1:2] not in (b"V", b"M"):
         raise ValueError("unknown record token %r" % token)
     dtype = np.dtype("<f4") if token[:1] == b"F" else np.dtype("<f8")
     is_matrix = token[1:2] == b"M"
@@ -57,7 +60,10 @@ def _read_header(f):
 
 
 def _read_record(f, row_offset=0, num_rows=0):
-    dtype, is_matrix, rows, cols = _read_header(f)
+    head = _read_header(f)
+    if head[0] == "compressed":
+        return kaldi_compressed.read(f, head[1], row_offset, num_rows)
+    dtype, is_matrix, rows, cols = head
     if not is_matrix:
         return np.frombuffer(f.read(cols * dtype.itemsize), dtype=dtype)
     assert row_offset <= rows, "row_offset (%d) > num_rows (%d)" % (row_offset, rows)
@@ -130,7 +136,11 @@ class RandomAccessArkDataReader(object):
                 continue
             f = self._file(self.archive_idx[p])
             f.seek(self.scp.offset[p], 0)
-            _, is_matrix, rows, cols = _read_header(f)
+            head = _read_header(f)
+            if head[0] == "compressed":
+                is_matrix, (rows, cols) = True, kaldi_compressed.read_shape(f, head[1], skip=False)
+            else:
+                _, is_matrix, rows, cols = head
             if is_matrix:
                 first, count = _combine_ranges(None if self.scp.range_spec is None else self.scp.range_spec[p], 0, 0)
                 rows = count if count > 0 else rows - first
@@ -157,6 +167,10 @@ class RandomAccessArkDataReader(object):
         if len(pos) == 0 or np.any(pos < 0) or self.scp.range_spec is not None:
             return None
         if not (np.isscalar(row_offset) and row_offset == 0 and np.isscalar(num_rows) and num_rows == 0):
+            return None
+        f = self._file(self.archive_idx[pos[0]])
+        f.seek(self.scp.offset[pos[0]], 0)
+        if f.read(3)[2:3] == b"C":  # a compressed matrix: decoded record by record
             return None
         lib = _lib.load()
         rows, cols, width, is_mat = (ctypes.c_int32() for _ in range(4))
@@ -246,12 +260,14 @@ class RandomAccessArkDataReader(object):
 class ArkDataWriter(object):
     """Writes records `key \\0B<token><dims><data>` and, optionally, the scp line of each
     (ark_data_writer.py:15-120; kaldi_matrix.py:163-178).  Arrays are stored as float_save()
-    (float32) like the reference does; binary and uncompressed only."""
+    (float32) like the reference does; with compress, matrices are stored in one of Kaldi's compressed
+    formats (compression_method: see kaldi_compressed.METHOD_FORMAT, or "auto").  Binary only."""
 
     def __init__(self, archive_path, script_path=None, binary=True, flush=False, compress=False,
                  compression_method="auto", scp_sep=" "):
-        if not binary or compress:
-            raise NotImplementedError("only binary, uncompressed archives are written")
+        if not binary:
+            raise NotImplementedError("only binary archives are written")
+        self.compress, self.compression_method = bool(compress), compression_method
         self.archive_path, self.script_path, self.scp_sep, self._flush = archive_path, script_path, scp_sep, flush
         for p in (archive_path, script_path):
             d = os.path.dirname(p) if p else ""
@@ -287,9 +303,12 @@ class ArkDataWriter(object):
             assert len(key) > 0 and not any(c.isspace() for c in key), "Token %s not valid" % key
             x = np.ascontiguousarray(x, dtype=float_save())
             assert x.ndim in (1, 2)
-            token = (b"F" if x.dtype == np.float32 else b"D") + (b"V " if x.ndim == 1 else b"M ")
             head = key.encode() + b" "
-            body = _MARK + token + b"".join(struct.pack("<bi", 4, n) for n in x.shape) + x.tobytes()
+            if self.compress:
+                body = _MARK + kaldi_compressed.compress(x, self.compression_method)
+            else:
+                token = (b"F" if x.dtype == np.float32 else b"D") + (b"V " if x.ndim == 1 else b"M ")
+                body = _MARK + token + b"".join(struct.pack("<bi", 4, n) for n in x.shape) + x.tobytes()
             lines.append("%s%s%s:%d\n" % (key, self.scp_sep, self.archive_path, pos + len(head)))
             chunks += [head, body]
             pos += len(head) + len(body)
