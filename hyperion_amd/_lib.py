@@ -141,6 +141,9 @@ SIGNATURES = {
                                         c_void_p, c_void_p, i64, c_void_p]),
     "hypmi_gram_f64": (ctypes.c_int, [c_void_p, i64, i64, ctypes.c_int, c_void_p, c_void_p, i64, c_void_p,
                                       c_void_p]),
+    "hypmi_gram_f64_workspace_bytes": (i64, [i64, ctypes.c_int]),
+    "hypmi_gram_f64_ordered": (ctypes.c_int, [c_void_p, i64, i64, ctypes.c_int, c_void_p, c_void_p, i64, c_void_p,
+                                              c_void_p, i64, c_void_p]),
     "hypmi_pool_rows_f64": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, c_void_p, c_void_p, i64, c_void_p,
                                            c_void_p, i64, c_void_p]),
     "hypmi_gemm_nt_f64": (ctypes.c_int, [c_void_p, i64, i64, c_void_p, i64, i64, ctypes.c_int, c_void_p,

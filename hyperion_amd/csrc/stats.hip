@@ -8,7 +8,9 @@
 // wave owns a 64 x 64 block of C (4 x 4 tiles) and a range of samples; its operands come straight
 // from global memory in operand layout (lane l reads feature f0 + (l & 15) of sample s0 + (l >> 4):
 // four 128-byte row segments per load), the next step's eight loads are in flight while the sixteen
-// MFMAs of the current one run, and the block is added to C with float64 atomics at the end.  Only
+// MFMAs of the current one run, and the block is added to C with float64 atomics at the end -- or, in
+// ordered mode, written to the wave's own slot of a workspace and summed in slot order by a second
+// kernel, which makes the result the same from run to run.  Only
 // blocks on or above the diagonal are computed; off-diagonal blocks are added to both halves.
 // A wave that ends early returns before anything collective: the kernel has no barrier.
 //
@@ -24,7 +26,7 @@ constexpr int GB = 64;  // features per block side
 __global__ __launch_bounds__(256) void gram_f64_kernel(const double* __restrict__ X, int64_t ldx, int64_t n,
                                                        int d, const double* __restrict__ w,
                                                        int64_t samples_per_wave, double* __restrict__ C,
-                                                       int64_t ldc) {
+                                                       int64_t ldc, double* __restrict__ partial) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     // blockIdx.x runs over the block pairs (bi <= bj) row by row
@@ -95,6 +97,18 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(const double* __restrict_
         }
     }
     // D layout: column = lane & 15, row = (lane >> 4) + 4 * reg
+    if (partial) {
+        // ordered mode: the block goes to this wave's own slot (pair, slab, wave); gram_reduce_kernel
+        // adds the slots of a pair in slot order, so the sum does not depend on scheduling
+        double* slot = partial + (((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave) * (GB * GB);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) slot[(16 * i + l4 + 4 * e) * GB + 16 * j + l15] = acc[i][j][e];
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -109,17 +123,67 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(const double* __restrict_
             }
 }
 
-// F[c] += sum_s w_s X[s, c]: one thread per column and row slab, coalesced across columns.
+// Adds the slots of every block pair in slot order into C (both halves for off-diagonal pairs).
+// One thread per element of a 64 x 64 block.
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ partial, int64_t slots,
+                                                          int d, double* __restrict__ C, int64_t ldc) {
+    const int nblk = (d + GB - 1) / GB;
+    int bi = 0, bj = (int)blockIdx.x;
+    while (bj >= nblk - bi) {
+        bj -= nblk - bi;
+        ++bi;
+    }
+    bj += bi;
+    const int e = blockIdx.y * 256 + threadIdx.x;  // element of the block
+    const int f = bi * GB + e / GB, g = bj * GB + e % GB;
+    const double* p = partial + (int64_t)blockIdx.x * slots * (GB * GB) + e;
+    double sum = 0.0;
+    for (int64_t k = 0; k < slots; ++k) sum += p[k * (GB * GB)];
+    if (f < d && g < d) {
+        C[(int64_t)f * ldc + g] = sum;
+        if (bi != bj) C[(int64_t)g * ldc + f] = sum;
+    }
+}
+
+// F[c] += sum_s w_s X[s, c]: one thread per column and row slab, coalesced across columns.  With
+// `partial` the slab sums go to partial[slab, c] and colsum_reduce_kernel adds them in slab order.
 __global__ __launch_bounds__(256) void colsum_f64_kernel(const double* __restrict__ X, int64_t ldx, int64_t n,
                                                          int d, const double* __restrict__ w,
-                                                         int64_t rows_per_block, double* __restrict__ F) {
+                                                         int64_t rows_per_block, double* __restrict__ F,
+                                                         double* __restrict__ partial) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= d) return;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
     double s = 0.0;
     for (int64_t r = r0; r < r1; ++r) s += X[r * ldx + c] * (w ? w[r] : 1.0);
-    if (r1 > r0) atomicAdd(&F[c], s);
+    if (partial) partial[(int64_t)blockIdx.y * d + c] = s;
+    else if (r1 > r0) atomicAdd(&F[c], s);
+}
+
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const double* __restrict__ partial, int64_t slabs,
+                                                            int d, double* __restrict__ F) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    double s = 0.0;
+    for (int64_t k = 0; k < slabs; ++k) s += partial[k * d + c];
+    F[c] = s;
+}
+
+// Sum of m doubles in a fixed order: thread t adds elements t, t + 256, ... and the 256 partial sums
+// are added pairwise in a fixed tree.  One workgroup.
+__global__ __launch_bounds__(256) void ordered_sum_kernel(const double* __restrict__ v, int64_t m,
+                                                          double* __restrict__ out) {
+    __shared__ double part[256];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < m; i += 256) s += v[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = part[0];
 }
 
 // Latent posterior of the two-covariance model in the eigenbasis of V W V^T = Q diag(lam) Q^T, where
@@ -168,40 +232,89 @@ extern "C" int hypmi_splda_posterior(double* T, int64_t m, int64_t ldt, int K, c
     HYPMI_REQUIRE(T && N && lam, "splda_posterior: null pointer");
     int64_t blocks = (m + 3) / 4;
     if (blocks > 4096) blocks = 4096;
+    // with the per-class values kept, their total is taken from them in a fixed order (same bits from run
+    // to run); without, the waves add their shares with atomics
     hipLaunchKernelGGL(splda_posterior_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, T, ldt, m, K, N, lam,
-                       logpy, logpy_sum);
+                       logpy, logpy ? nullptr : logpy_sum);
+    if (logpy && logpy_sum)
+        hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(256), 0, stream, logpy, m, logpy_sum);
     HYPMI_HIP(hipGetLastError());
     return HYPMI_OK;
 }
 
-extern "C" int hypmi_gram_f64(const double* X, int64_t n, int64_t ldx, int d, const double* w, double* C,
-                              int64_t ldc, double* F, void* stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    HYPMI_REQUIRE(n >= 0 && d > 0 && ldx >= d && ldc >= d, "gram_f64: bad shape");
-    HYPMI_REQUIRE(C, "gram_f64: null result");
+namespace {
+struct GramGrid {
+    int npairs;
+    int64_t chunks, samples_per_wave, slabs, rows_per_block;
+};
+
+GramGrid gram_grid(int64_t n, int d) {
+    GramGrid g;
+    const int nb = (d + GB - 1) / GB;
+    g.npairs = nb * (nb + 1) / 2;  // blocks on and above the diagonal
+    // about 2048 workgroups in all; a wave walks at least 64 samples
+    g.chunks = (2048 + g.npairs - 1) / g.npairs;
+    const int64_t max_chunks = (n + 4 * 64 - 1) / (4 * 64);
+    if (g.chunks > max_chunks) g.chunks = max_chunks;
+    if (g.chunks > 65535) g.chunks = 65535;
+    if (g.chunks < 1) g.chunks = 1;
+    g.samples_per_wave = (n + g.chunks * 4 - 1) / (g.chunks * 4);
+    g.samples_per_wave = (g.samples_per_wave + 3) / 4 * 4;
+    g.slabs = (n + 4095) / 4096;
+    if (g.slabs > 65535) g.slabs = 65535;
+    if (g.slabs < 1) g.slabs = 1;
+    g.rows_per_block = (n + g.slabs - 1) / g.slabs;
+    return g;
+}
+
+int gram_run(const double* X, int64_t n, int64_t ldx, int d, const double* w, double* C, int64_t ldc, double* F,
+             double* ws, hipStream_t stream) {
     HYPMI_HIP(hipMemsetAsync(C, 0, (size_t)d * (size_t)ldc * sizeof(double), stream));
     if (F) HYPMI_HIP(hipMemsetAsync(F, 0, (size_t)d * sizeof(double), stream));
     if (n == 0) return HYPMI_OK;
     HYPMI_REQUIRE(X, "gram_f64: null pointer");
-    const int nb = (d + GB - 1) / GB;
-    const int npairs = nb * (nb + 1) / 2;  // blocks on and above the diagonal
-    // about 2048 workgroups in all; a wave walks at least 64 samples
-    int64_t chunks = (2048 + npairs - 1) / npairs;
-    const int64_t max_chunks = (n + 4 * 64 - 1) / (4 * 64);
-    if (chunks > max_chunks) chunks = max_chunks;
-    if (chunks > 65535) chunks = 65535;
-    if (chunks < 1) chunks = 1;
-    int64_t samples_per_wave = (n + chunks * 4 - 1) / (chunks * 4);
-    samples_per_wave = (samples_per_wave + 3) / 4 * 4;
-    hipLaunchKernelGGL(gram_f64_kernel, dim3((unsigned)npairs, (unsigned)chunks), dim3(256), 0, stream, X, ldx, n,
-                       d, w, samples_per_wave, C, ldc);
+    const GramGrid g = gram_grid(n, d);
+    const int64_t slots = g.chunks * 4;
+    const size_t gram_doubles = (size_t)g.npairs * slots * GB * GB;
+    if (ws) HYPMI_HIP(hipMemsetAsync(ws, 0, gram_doubles * sizeof(double), stream));  // waves without samples
+    hipLaunchKernelGGL(gram_f64_kernel, dim3((unsigned)g.npairs, (unsigned)g.chunks), dim3(256), 0, stream, X, ldx, n,
+                       d, w, g.samples_per_wave, C, ldc, ws);
+    if (ws)
+        hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)g.npairs, GB * GB / 256), dim3(256), 0, stream, ws,
+                           slots, d, C, ldc);
     if (F) {
-        int64_t slabs = (n + 4095) / 4096;
-        if (slabs > 65535) slabs = 65535;
-        const int64_t rows_per_block = (n + slabs - 1) / slabs;
-        hipLaunchKernelGGL(colsum_f64_kernel, dim3((unsigned)((d + 255) / 256), (unsigned)slabs), dim3(256), 0,
-                           stream, X, ldx, n, d, w, rows_per_block, F);
+        double* fpart = ws ? ws + gram_doubles : nullptr;
+        hipLaunchKernelGGL(colsum_f64_kernel, dim3((unsigned)((d + 255) / 256), (unsigned)g.slabs), dim3(256), 0,
+                           stream, X, ldx, n, d, w, g.rows_per_block, F, fpart);
+        if (ws)
+            hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, stream, fpart,
+                               g.slabs, d, F);
     }
     HYPMI_HIP(hipGetLastError());
     return HYPMI_OK;
+}
+}  // namespace
+
+extern "C" int hypmi_gram_f64(const double* X, int64_t n, int64_t ldx, int d, const double* w, double* C,
+                              int64_t ldc, double* F, void* stream_) {
+    HYPMI_REQUIRE(n >= 0 && d > 0 && ldx >= d && ldc >= d, "gram_f64: bad shape");
+    HYPMI_REQUIRE(C, "gram_f64: null result");
+    return gram_run(X, n, ldx, d, w, C, ldc, F, nullptr, static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int64_t hypmi_gram_f64_workspace_bytes(int64_t n, int d) {
+    if (n <= 0 || d <= 0) return 0;
+    const GramGrid g = gram_grid(n, d);
+    return ((int64_t)g.npairs * g.chunks * 4 * GB * GB + g.slabs * (int64_t)d) * (int64_t)sizeof(double);
+}
+
+extern "C" int hypmi_gram_f64_ordered(const double* X, int64_t n, int64_t ldx, int d, const double* w, double* C,
+                                      int64_t ldc, double* F, void* ws, int64_t ws_bytes, void* stream_) {
+    HYPMI_REQUIRE(n >= 0 && d > 0 && ldx >= d && ldc >= d, "gram_f64_ordered: bad shape");
+    HYPMI_REQUIRE(C, "gram_f64_ordered: null result");
+    const int64_t need = hypmi_gram_f64_workspace_bytes(n, d);
+    HYPMI_REQUIRE(need == 0 || (ws && ws_bytes >= need), "gram_f64_ordered: workspace too small (%lld < %lld bytes)",
+                  (long long)ws_bytes, (long long)need);
+    return gram_run(X, n, ldx, d, w, C, ldc, F, n > 0 ? static_cast<double*>(ws) : nullptr,
+                    static_cast<hipStream_t>(stream_));
 }

@@ -139,10 +139,15 @@ def gram64(x, w=None):
     W = None if w is None else _vec64(w, n)
     C = torch.empty((d, d), dtype=torch.float64, device="cuda")
     F = torch.empty((d,), dtype=torch.float64, device="cuda")
-    _lib.check(_lib.load().hypmi_gram_f64(_ptr(X), n, X.stride(0) if n > 1 else d, d,
+    lib = _lib.load()
+    nbytes = lib.hypmi_gram_f64_workspace_bytes(n, d)
+    ws = torch.empty(max(nbytes // 8, 1), dtype=torch.float64, device="cuda")
+    # partial blocks are added in a fixed order: the statistics (and what is trained from them) are the
+    # same bits from run to run
+    _lib.check(lib.hypmi_gram_f64_ordered(_ptr(X), n, X.stride(0) if n > 1 else d, d,
                                           ctypes.c_void_p(0) if W is None else _ptr(W), _ptr(C), d, _ptr(F),
-                                          stream_ptr()))
-    # the two halves are summed by different workgroups in different orders: make them one matrix
+                                          _ptr(ws), nbytes, stream_ptr()))
+    # with row weights the two triangles of a diagonal block round x_f (w x_g) and x_g (w x_f) differently
     return 0.5 * (C + C.T), F
 
 

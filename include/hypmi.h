@@ -359,6 +359,13 @@ int hypmi_norm_apply(const float* S, int64_t lds, int64_t ne, int64_t nt, const 
 int hypmi_gram_f64(const double* X, int64_t n, int64_t ldx, int d, const double* w, double* C,
                    int64_t ldc, double* F, void* stream);
 
+/* The same sums added in a fixed order (same bits from run to run, like the reference's serial sums):
+ * every wave writes its partial block to its own slot of the workspace and a second kernel adds the
+ * slots in order.  workspace: hypmi_gram_f64_workspace_bytes(n, d) bytes of device memory. */
+int64_t hypmi_gram_f64_workspace_bytes(int64_t n, int d);
+int hypmi_gram_f64_ordered(const double* X, int64_t n, int64_t ldx, int d, const double* w, double* C,
+                           int64_t ldc, double* F, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Float64 class sums for training: out[g] = sum over the rows of class g of w_r x_r (w NULL: 1), rows
  * listed by order / offsets as in hypmi_pool_rows.  F of PLDABase.compute_stats_hard
  * (hyperion/pdfs/plda/plda_base.py:258-266) at the reference's precision. */

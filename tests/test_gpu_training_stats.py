@@ -23,6 +23,48 @@ def test_gram_matches_float64(n, d, weighted):
     assert np.array_equal(C.cpu().numpy(), C.cpu().numpy().T)  # both halves come from the same sums
 
 
+def test_statistics_and_training_are_the_same_bits_from_run_to_run():
+    """Partial sums are added in a fixed order (like the reference's serial sums): repeated runs of the
+    Gram statistics and of an EM fit give identical bits; the atomic variant of the Gram kernel agrees
+    with the ordered one to rounding."""
+    import ctypes
+
+    import torch
+
+    import synth
+    from hyperion_amd import _lib, engine
+    from hyperion_amd.pdfs.plda import FRPLDA, PLDA, SPLDA
+
+    rng = np.random.RandomState(3)
+    x = rng.randn(30000, 200) * 3 + 1
+    w = rng.uniform(0.5, 2.0, 30000)
+    runs = [engine.gram64(x, w) for _ in range(3)]
+    for C, F in runs[1:]:
+        assert torch.equal(C, runs[0][0]) and torch.equal(F, runs[0][1])
+    X, W = engine.upload64(x), engine.upload64(w[:, None])[:, 0].contiguous()
+    Ca = torch.empty((200, 200), dtype=torch.float64, device="cuda")
+    Fa = torch.empty((200,), dtype=torch.float64, device="cuda")
+    _lib.check(_lib.load().hypmi_gram_f64(engine._ptr(X), 30000, 200, 200, engine._ptr(W), engine._ptr(Ca), 200,
+                                          engine._ptr(Fa), engine.stream_ptr()))
+    assert torch.allclose(0.5 * (Ca + Ca.T), runs[0][0], rtol=1e-12, atol=1e-9)
+    assert torch.allclose(Fa, runs[0][1], rtol=1e-12, atol=1e-9)
+
+    m = synth.make_splda(40, 12)
+    xs = rng.randn(4000, 40)
+    ids = np.repeat(np.arange(500), 8)
+    for make in (lambda: SPLDA(y_dim=12), lambda: FRPLDA(), lambda: PLDA(y_dim=12, z_dim=6)):
+        fits = []
+        for _ in range(2):
+            model = make()
+            elbo = model.fit(xs, class_ids=ids, epochs=4)
+            params = [np.array(v) for k, v in sorted(vars(model).items())
+                      if isinstance(v, np.ndarray) and not k.startswith("_")]
+            fits.append([np.array(elbo[0] if isinstance(elbo, tuple) else elbo)] + params)
+        assert len(fits[0]) >= 4
+        for a, b in zip(fits[0], fits[1]):
+            assert np.array_equal(a, b), type(model).__name__
+
+
 def test_gram_of_nothing_and_of_pitched_rows():
     import torch
 
