@@ -444,8 +444,9 @@ def main_asnorm(args, cfg, chain, model, plda, preproc, world, rank, dist):
             "note": "cohort-statistics gather, %.0f %% of the step: one gathered fp32 (4 B) per (row, list, member) "
                     "from LDS-resident rows; peak = conflict-free LDS read rate (256 B/clk/CU).  The loop is bound "
                     "by instruction issue, not LDS bytes: per 8 gathered bytes a SIMD issues one address op, one "
-                    "ds_read_b64 and four plain f32 ops, measured floor 6.6 clk per wave-entry per CU = 0.30 of this "
-                    "peak (tools/probes/gather_rate.hip)"
+                    "ds_read_b64 and four plain f32 ops; the walk alone sustains 0.315 of this peak (12.7 us per "
+                    "round of 1024 lists, tools/gather_overhead.py), a workgroup pays 11 us on top for its row fill "
+                    "and the uneven finish of its waves"
                     % (100.0 * g["avg_launch_ms"] * g["launches_per_step"] / (dt * 1e3))}
     if "sink" in st:
         out["sink"] = st["sink"]
