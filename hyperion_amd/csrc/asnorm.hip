@@ -973,7 +973,12 @@ __global__ __launch_bounds__(GS_THREADS) void gather_stats_kernel(
 //   * every lane keeps GP_RING 16-byte index loads in flight over the flattened (list, group)
 //     sequence of its lists;
 //   * the lists arrive ordered by LDS bank class and rotated by lane (see bank_order in the top-k
-//     kernel), which removes most bank conflicts without any coordination between lists.
+//     kernel), which removes most bank conflicts without any coordination between lists;
+//   * the waves of a SIMD are served oldest first, which lets the first of them finish its lists well
+//     before the last and leaves the SIMD short of work at the end of every workgroup: each wave moves
+//     through the four issue-priority levels, one per list.
+// The walk alone runs at 12.7 us per round of 1024 lists on 2 x 20 000 floats (0.315 of the LDS read
+// rate); a workgroup pays about 11 us more for its row fill and the finish (tools/gather_overhead.py).
 // With a per-row pivot the variance is s2/k - (s1/k)^2 with s2/k up to GP_AMP times the variance; for
 // the few (row, list) pairs beyond that (a selection far out in the tail of its row, or constant)
 // the lane walks the list again around the list's own first member, which is what the general kernel
