@@ -1051,8 +1051,11 @@ __device__ __forceinline__ void moment_step(float& s1, float& s2, float v) {
     asm("v_fma_f32 %0, %1, %1, %0" : "+v"(s2) : "v"(v));
 }
 
-// The general walk of one list for the R rows in LDS, around the list's first member (fp32 shifted
-// moments: exact zero variance for a constant selection).  Cold path of gather_pivot_kernel.
+// The general walk of one list for R rows, around the list's first member (fp32 shifted moments: exact
+// zero variance for a constant selection).  Cold path of gather_pivot_kernel.  The values come from the
+// rows in global memory, not from the LDS copy: that copy is already rounded after the subtraction of
+// the row pivot, which is too coarse exactly for the selections that end up here (spread far below
+// their distance from the row's mean).
 template <int R>
 struct ShiftedMoments {
     float piv[R], s1[R], s2[R];
@@ -1061,21 +1064,23 @@ struct ShiftedMoments {
 // Returned by value (registers): taking the caller's accumulators by reference would put them in
 // scratch memory for the whole hot loop.
 template <int R>
-__device__ __noinline__ ShiftedMoments<R> list_moments_shifted(const char* xb, const uint4* lp, int64_t ldi, int k) {
-    typedef typename VecR<R>::type vec_t;
+__device__ __noinline__ ShiftedMoments<R> list_moments_shifted(const float* X, int64_t ldx, int64_t r0,
+                                                               int64_t n_rows, const uint4* lp, int64_t ldi, int k) {
     ShiftedMoments<R> m;
-    unpack<R>(*reinterpret_cast<const vec_t*>(xb + (size_t)(lp[0].x & 0xffffu) * (4 * R)), m.piv);
+    const float* row[R];
 #pragma unroll
-    for (int rr = 0; rr < R; ++rr) m.s1[rr] = m.s2[rr] = 0.f;
+    for (int rr = 0; rr < R; ++rr) {
+        row[rr] = X + (r0 + rr < n_rows ? r0 + rr : n_rows - 1) * ldx;
+        m.piv[rr] = row[rr][lp[0].x & 0xffffu];
+        m.s1[rr] = m.s2[rr] = 0.f;
+    }
     for (int j = 0; j < k; ++j) {
         const uint4 pk = lp[(int64_t)(j >> 3) * ldi];
         const unsigned w = (j & 4) ? ((j & 2) ? pk.w : pk.z) : ((j & 2) ? pk.y : pk.x);
         const unsigned c = (w >> (16 * (j & 1))) & 0xffffu;
-        float v[R];
-        unpack<R>(*reinterpret_cast<const vec_t*>(xb + (size_t)c * (4 * R)), v);
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
-            const float d = v[rr] - m.piv[rr];
+            const float d = row[rr][c] - m.piv[rr];
             m.s1[rr] += d;
             m.s2[rr] = fmaf(d, d, m.s2[rr]);
         }
@@ -1201,7 +1206,6 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
         }
     }
     __syncthreads();
-    const char* xb = reinterpret_cast<const char*>(xr);
     const unsigned xbase = __builtin_amdgcn_readfirstlane(lds_address(xr));
 
     const int G = (k + 7) >> 3, krem = k & 7;
@@ -1316,15 +1320,15 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
             /* The sums carry fp32 rounding (about 1e-6 relative); so does this arithmetic. */                  \
             const int64_t q = q0 + tid + (int64_t)l * GS_THREADS;                                               \
             const bool live_q = q < q1;                                                                         \
-            float lp[R];                                                                                        \
+            float lp[R]; /* what the moments are taken around: the row pivot, or after a redo the list's own */ \
             bool redo = false;                                                                                  \
             _Pragma("unroll") for (int rr = 0; rr < R; ++rr) {                                                  \
-                lp[rr] = 0.f;                                                                                   \
+                lp[rr] = rowpiv[rr];                                                                            \
                 const float md = s1[rr] * inv_k, ms = s2[rr] * inv_k;                                           \
                 redo |= fmaf(-md, md, ms) * GP_AMP < ms; /* false for NaN: those stay NaN */                    \
             }                                                                                                   \
             if (redo && live_q) {                                                                               \
-                const ShiftedMoments<R> m = list_moments_shifted<R>(xb, base + q, ldi, k);                      \
+                const ShiftedMoments<R> m = list_moments_shifted<R>(X, ldx, r0, n_rows, base + q, ldi, k);      \
                 _Pragma("unroll") for (int rr = 0; rr < R; ++rr) {                                              \
                     lp[rr] = m.piv[rr];                                                                         \
                     s1[rr] = m.s1[rr];                                                                          \
@@ -1339,7 +1343,7 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
                 /* 1 / max(sqrt(var), floor): v_rsq_f32 is good to one unit in the last place */                \
                 const float is = var < floor2 ? inv_floor : __builtin_amdgcn_rsqf(var);                         \
                 if (live_q && r0 + rr < n_rows) {                                                               \
-                    const float m = (rowpiv[rr] + lp[rr]) + md;                                                 \
+                    const float m = lp[rr] + md;                                                                \
                     if (APPLY) {                                                                                \
                         ap.out[(r0 + rr) * ap.ldo + q] =                                                        \
                             asnorm_value(ps[rr], m, is, lds_vec_elem<R>(pm, rr), lds_vec_elem<R>(pi, rr));      \

@@ -1027,3 +1027,29 @@ def test_topk_lazy_exact_rows_equal_full_exact_rows():
     S64 = (Gr64[:, :-2] @ Gc64[:, :-2].T + Gr64[:, -2:-1] + Gc64[:, -2][None, :]).cpu().numpy()
     order = np.argsort(-S64, axis=1, kind="stable")[:, 3:3 + k]
     assert np.array_equal(np.sort(order, axis=1), got)
+
+
+@pytest.mark.gpu
+def test_gather_stats_two_close_members_far_from_the_row_mean():
+    """Lists of two members whose values differ by 1e-4 of their distance from the row's mean: the
+    pair is recomputed from the rows themselves (the LDS copy, shifted by the row pivot, is already
+    rounded to about 1e-5 of that difference's scale), so the standard deviation keeps its digits."""
+    import torch
+
+    from hyperion_amd.score_norm.adapt_s_norm import gather_stats
+
+    rng = np.random.RandomState(8)
+    rows, nc, lists = 6, 5000, 300
+    X = (rng.randn(rows, nc) * 20 + 40).astype(np.float32)
+    pairs = rng.choice(nc // 2, size=lists, replace=False)
+    a, b = 2 * pairs, 2 * pairs + 1
+    X[:, b] = X[:, a] + (0.004 * rng.rand(rows, lists) + 0.001).astype(np.float32)  # close pairs, up to 60 away
+    idx = np.zeros((1, lists, 8), dtype=np.uint16)
+    idx[0, :, 0], idx[0, :, 1] = a, b
+    mean, istd, _ = gather_stats(torch.from_numpy(X).cuda(), None, torch.from_numpy(idx.view(np.int16)).cuda(),
+                                 lists, 1e-5, 2)
+    x64 = X.astype(np.float64)
+    sel = np.stack([x64[:, a], x64[:, b]], axis=2)
+    s_ref = np.maximum(sel.std(axis=2), 1e-5)
+    assert np.max(np.abs(istd[:, :lists].cpu().numpy() * s_ref - 1.0)) <= 2e-6
+    assert np.max(np.abs(mean[:, :lists].cpu().numpy() - sel.mean(axis=2))) <= 4e-6 * 60
