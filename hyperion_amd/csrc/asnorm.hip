@@ -475,10 +475,9 @@ struct TopkRegs {
 };
 
 template <int ITEMS>
-__global__ __launch_bounds__(TR_THREADS) void topk_rows_reg_kernel(const float* __restrict__ A, int64_t lda,
-                                                                   int nc, int k, int discard,
-                                                                   uint16_t* __restrict__ idx8, int64_t ldi,
-                                                                   ExactSrc ex) {
+__device__ __forceinline__ void topk_rows_reg_body(const float* __restrict__ A, int64_t lda, int nc, int k,
+                                                   int discard, uint16_t* __restrict__ idx8, int64_t ldi,
+                                                   const ExactSrc& ex) {
     __shared__ __attribute__((aligned(16))) TopkShared sh;
     __shared__ unsigned tab[TR_WAVES * ((ITEMS + 63) / 64) * 64];  // per (wave, item) counts for the ordered compaction
     __shared__ double exact_s[TK_CAND];
@@ -804,11 +803,41 @@ __global__ __launch_bounds__(TR_THREADS) void topk_rows_reg_kernel(const float* 
     }
 }
 
+// The kernel is bound by instruction issue and its barriers: more resident waves help as long as the keys
+// still fit the registers that leaves.  Measured for 20 000-member rows (80 keys per thread): 7.3 ms per
+// three chunks at two waves per SIMD (what the compiler chooses on its own), 5.9 at three, 5.3 at four.
+template <int ITEMS>
+__global__ __launch_bounds__(TR_THREADS) void topk_rows_reg_kernel(const float* __restrict__ A, int64_t lda, int nc,
+                                                                   int k, int discard, uint16_t* __restrict__ idx8,
+                                                                   int64_t ldi, ExactSrc ex) {
+    topk_rows_reg_body<ITEMS>(A, lda, nc, k, discard, idx8, ldi, ex);
+}
+template <int ITEMS>
+__global__ __launch_bounds__(TR_THREADS) __attribute__((amdgpu_waves_per_eu(3))) void topk_rows_reg_kernel_w3(
+    const float* __restrict__ A, int64_t lda, int nc, int k, int discard, uint16_t* __restrict__ idx8, int64_t ldi,
+    ExactSrc ex) {
+    topk_rows_reg_body<ITEMS>(A, lda, nc, k, discard, idx8, ldi, ex);
+}
+template <int ITEMS>
+__global__ __launch_bounds__(TR_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void topk_rows_reg_kernel_w4(
+    const float* __restrict__ A, int64_t lda, int nc, int k, int discard, uint16_t* __restrict__ idx8, int64_t ldi,
+    ExactSrc ex) {
+    topk_rows_reg_body<ITEMS>(A, lda, nc, k, discard, idx8, ldi, ex);
+}
+
 template <int ITEMS>
 void launch_topk_reg(const float* A, int64_t n_rows, int nc, int64_t lda, int k, int discard, uint16_t* idx_t,
                      int64_t ldi, const ExactSrc& ex, hipStream_t stream) {
-    hipLaunchKernelGGL((topk_rows_reg_kernel<ITEMS>), dim3((unsigned)n_rows), dim3(TR_THREADS), 0, stream, A,
-                       lda, nc, k, discard, idx_t, ldi, ex);
+    // as many waves per SIMD as the keys leave registers for without spilling
+    if constexpr (ITEMS <= 80)
+        hipLaunchKernelGGL((topk_rows_reg_kernel_w4<ITEMS>), dim3((unsigned)n_rows), dim3(TR_THREADS), 0, stream, A,
+                           lda, nc, k, discard, idx_t, ldi, ex);
+    else if constexpr (ITEMS <= 96)
+        hipLaunchKernelGGL((topk_rows_reg_kernel_w3<ITEMS>), dim3((unsigned)n_rows), dim3(TR_THREADS), 0, stream, A,
+                           lda, nc, k, discard, idx_t, ldi, ex);
+    else
+        hipLaunchKernelGGL((topk_rows_reg_kernel<ITEMS>), dim3((unsigned)n_rows), dim3(TR_THREADS), 0, stream, A,
+                           lda, nc, k, discard, idx_t, ldi, ex);
 }
 
 // R rows of X per workgroup, held in LDS interleaved (xr[c * R + rr]); lanes over lists q.
