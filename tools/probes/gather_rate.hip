@@ -139,7 +139,8 @@ __global__ __launch_bounds__(GS) void gather(const float* __restrict__ X, int64_
 
 // Flattened (list, group) stream per lane with a ring of D index loads in flight; pivot subtracted at
 // the fill; plain adds / fmas; one v_mad_u32_u16 per address.  MODE 0: both moments, 1: sum of
-// squares only, 2: LDS reads only.
+// squares only, 2: LDS reads only, 3: the sums of squares on the matrix pipe (v_mfma_f32_4x4x1: a lane's
+// own square is the diagonal entry of its 4 x 4 block), 4: one of the two sums of squares there.
 template <int D, int MODE>
 __global__ __launch_bounds__(GS) void gather2(const float* __restrict__ X, int64_t ldx, int nc,
                                               const uint16_t* __restrict__ idx8, int64_t ldi, int k, int64_t Q,
@@ -168,6 +169,8 @@ __global__ __launch_bounds__(GS) void gather2(const float* __restrict__ X, int64
         if (++g_ld == G) { g_ld = 0; p += wrap; }
     }
     float s1a = 0.f, s1b = 0.f, s2a = 0.f, s2b = 0.f;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v ma = {0.f, 0.f, 0.f, 0.f}, mb = {0.f, 0.f, 0.f, 0.f};
     unsigned acc_or = 0;
     int g = 0;
     int64_t q = tid;
@@ -176,11 +179,17 @@ __global__ __launch_bounds__(GS) void gather2(const float* __restrict__ X, int64
         if (hi) asm("v_mad_u32_u16 %0, %1, 8, 0 op_sel:[1,0,0,0]" : "=v"(addr) : "v"(w));
         else asm("v_mad_u32_u16 %0, %1, 8, 0" : "=v"(addr) : "v"(w));
         const float2 v = *reinterpret_cast<const float2*>(xb + addr);
-        if (MODE == 0) {
+        if (MODE == 0 || MODE >= 3) {
             asm("v_add_f32 %0, %1, %0" : "+v"(s1a) : "v"(v.x));
             asm("v_add_f32 %0, %1, %0" : "+v"(s1b) : "v"(v.y));
         }
-        if (MODE <= 1) {
+        if (MODE == 3) {
+            ma = __builtin_amdgcn_mfma_f32_4x4x1f32(v.x, v.x, ma, 0, 0, 0);
+            mb = __builtin_amdgcn_mfma_f32_4x4x1f32(v.y, v.y, mb, 0, 0, 0);
+        } else if (MODE == 4) {
+            asm("v_fma_f32 %0, %1, %1, %0" : "+v"(s2a) : "v"(v.x));
+            mb = __builtin_amdgcn_mfma_f32_4x4x1f32(v.y, v.y, mb, 0, 0, 0);
+        } else if (MODE <= 1) {
             asm("v_fma_f32 %0, %1, %1, %0" : "+v"(s2a) : "v"(v.x));
             asm("v_fma_f32 %0, %1, %1, %0" : "+v"(s2b) : "v"(v.y));
         } else {
@@ -201,6 +210,12 @@ __global__ __launch_bounds__(GS) void gather2(const float* __restrict__ X, int64
                 add(pk.z, 0); add(pk.z, 1); add(pk.w, 0); add(pk.w, 1);
                 if (++g == G) {
                     if (MODE == 2) s1a = __uint_as_float(acc_or);
+                    if (MODE >= 3) {
+                        const int j = tid & 3;
+                        s2b = j == 0 ? mb[0] : j == 1 ? mb[1] : j == 2 ? mb[2] : mb[3];
+                        if (MODE == 3) s2a = j == 0 ? ma[0] : j == 1 ? ma[1] : j == 2 ? ma[2] : ma[3];
+                        ma = mb = f4v{0.f, 0.f, 0.f, 0.f};
+                    }
                     const float m0 = s1a / k, m1 = s1b / k;
                     mean[r0 * ldo + q] = m0 + rp0;
                     mean[(r0 + 1) * ldo + q] = m1 + rp1;
@@ -398,7 +413,7 @@ int main(int argc, char** argv) {
     }
         printf("pattern: %s (%d rows x %lld lists x %d)\n", pats[pat], rows, (long long)Q, k);
         GATHER(0)
-        GATHER2(4, 0, 0) GATHER2(8, 0, 0) GATHER2(8, 1, 0) GATHER2(8, 2, 0)
+        GATHER2(4, 0, 0) GATHER2(8, 0, 0) GATHER2(8, 1, 0) GATHER2(8, 2, 0) GATHER2(4, 3, 0) GATHER2(4, 4, 0)
         {   // 32-bit byte-offset lists
             std::vector<uint32_t> h4((size_t)(k / 4) * Q * 4);
             for (int64_t q = 0; q < Q; ++q)
