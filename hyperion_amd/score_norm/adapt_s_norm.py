@@ -171,29 +171,41 @@ class AdaptSNorm(ScoreNorm):
     def predict(self, scores, scores_coh_test, scores_enr_coh, mask_coh_test=None, mask_enr_coh=None):
         torch = engine.require_gpu()
         S = dev_matrix(scores)
-        CT = dev_matrix(scores_coh_test)
-        EC = dev_matrix(scores_enr_coh)
-        assert EC.shape[1] == CT.shape[0]
-        assert self.nbest_discard < EC.shape[1]
-        assert EC.shape[0] == S.shape[0] and CT.shape[1] == S.shape[1]
+        host_ec = not isinstance(scores_enr_coh, torch.Tensor)
+        host_ct = not isinstance(scores_coh_test, torch.Tensor)
+        wide = lambda a: np.asarray(a).dtype.itemsize > 4  # noqa: E731  (fp32 arrays lose nothing on the device)
+        # Cohort scores that arrive as host arrays are ranked in fp32 on the device; members whose fp32
+        # roundings collide at a selection boundary are re-decided from the float64 values.  Those go
+        # to the device once, as float64, and are narrowed there.
+        exact_ec = exact_tc = None
         m_ec = m_tc = None
-        if mask_coh_test is not None:
-            m_ct = dev_mask(mask_coh_test, CT.shape)
-            CT = CT.clone() if isinstance(scores_coh_test, torch.Tensor) else CT
-            zero_masked(CT, m_ct)
-            m_tc = transpose_mask(m_ct)
+        if mask_enr_coh is None and host_ec and wide(scores_enr_coh):
+            E64 = engine.upload64(scores_enr_coh)
+            EC = engine.upload(E64)
+            exact_ec = {"A64": E64, "count": True}
+        else:
+            EC = dev_matrix(scores_enr_coh)
+        if mask_coh_test is None and host_ct and wide(scores_coh_test):
+            T64 = engine.upload64(scores_coh_test).t().contiguous()  # [test, cohort]
+            TC = engine.upload(T64)
+            exact_tc = {"A64": T64, "count": True}
+        else:
+            CT = dev_matrix(scores_coh_test)
+            assert CT.shape[1] == S.shape[1]
+            if mask_coh_test is not None:
+                m_ct = dev_mask(mask_coh_test, CT.shape)
+                CT = CT.clone() if not host_ct else CT
+                zero_masked(CT, m_ct)
+                m_tc = transpose_mask(m_ct)
+            TC = transpose(CT)
+        assert EC.shape[1] == TC.shape[1]
+        assert self.nbest_discard < EC.shape[1]
+        assert EC.shape[0] == S.shape[0] and TC.shape[0] == S.shape[1]
         if mask_enr_coh is not None:
             m_ec = dev_mask(mask_enr_coh, EC.shape)
-            EC = EC.clone() if isinstance(scores_enr_coh, torch.Tensor) else EC
+            EC = EC.clone() if not host_ec else EC
             zero_masked(EC, m_ec)
-        # the cohort scores arrive in float64 and are ranked in fp32 on the device: members whose fp32
-        # roundings collide at a selection boundary are re-decided from the float64 values
-        exact_ec = exact_tc = None
-        if m_ec is None and not isinstance(scores_enr_coh, torch.Tensor):
-            exact_ec = {"A64": engine.upload64(scores_enr_coh), "count": True}
-        if m_tc is None and not isinstance(scores_coh_test, torch.Tensor):
-            exact_tc = {"A64": engine.upload64(scores_coh_test).t().contiguous(), "count": True}
-        out = adapt_s_norm_device(S, EC, transpose(CT), self.nbest, self.nbest_discard, m_ec, m_tc,
+        out = adapt_s_norm_device(S, EC, TC, self.nbest, self.nbest_discard, m_ec, m_tc,
                                   exact_ec=exact_ec, exact_tc=exact_tc)
         skipped = sum(e["counters"][1] for e in (exact_ec, exact_tc) if e is not None and "counters" in e)
         if skipped:

@@ -46,3 +46,24 @@ print("numpy API, refine (default)%8.1f ms   max relative error %.2e" % (t_api, 
 print("numpy API, refine=False    %8.1f ms" % t_norefine)
 print("device tensors in/out      %8.1f ms" % t_dev)
 print("  D2H of the fp32 matrix   %8.1f ms   host fp32 -> float64 %8.1f ms" % (t_d2h, t_cast))
+
+# ---- adaptive S-norm through the numpy API at an evaluation-set size --------------------------------
+from hyperion_amd.score_norm import AdaptSNorm  # noqa: E402
+
+ne, nt, nc, nbest = 2000, 20000, 5000, 200
+m2 = synth.make_splda(200, K)
+xe, xt, xc = (synth.length_norm(synth.sample_splda(m2, cnt, 1, seed)) for cnt, seed in ((ne, 1), (nt, 2), (nc, 3)))
+p2 = SPLDA(mu=m2["mu"], V=m2["V"], W=m2["W"])
+s_et, s_ct, s_ec = p2.llr_1vs1(xe, xt), p2.llr_1vs1(xc, xt), p2.llr_1vs1(xe, xc)
+AdaptSNorm(nbest=nbest).predict(s_et[:8, :8], s_ct[:, :8], s_ec[:8])  # first touch
+t_api, got = wall(lambda: AdaptSNorm(nbest=nbest).predict(s_et, s_ct, s_ec))
+sub = slice(0, 200)
+t_ref, ref = wall(lambda: O.adapt_s_norm(s_et[sub, :2000], s_ct[:, :2000], s_ec[sub], nbest, 0), 1)
+err = np.abs(got[sub, :2000] - ref) / np.maximum(np.abs(ref), 1)
+print("AdaptSNorm.predict(numpy float64) %d x %d, cohort %d, nbest %d: %8.1f ms = %.1f M scores/s   max error %.2e"
+      % (ne, nt, nc, nbest, t_api, ne * nt / t_api / 1e3, err.max()))
+print("  oracle on a 200 x 2000 slice: %8.1f ms = %.2f M scores/s" % (t_ref, 200 * 2000 / t_ref / 1e3))
+dev = [engine.upload(a) for a in (s_et, s_ec, np.ascontiguousarray(s_ct.T))]
+from hyperion_amd.score_norm.adapt_s_norm import adapt_s_norm_device  # noqa: E402
+t_dev, _ = wall(lambda: adapt_s_norm_device(dev[0], dev[1], dev[2], nbest, 0))
+print("  device tensors in/out (fp32):  %8.1f ms" % t_dev)
