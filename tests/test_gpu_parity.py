@@ -249,6 +249,38 @@ def test_adapt_s_norm_vs_oracle_large():
         assert err.max() <= 2e-5, err.max()
 
 
+@pytest.mark.parametrize("shape", [(37, 91, 640, 50, 0), (130, 70, 2100, 300, 3), (1100, 1200, 1030, 40, 0)])
+def test_adapt_s_norm_predict_every_input_kind(shape):
+    """float64 / float32, host arrays / device tensors, either mask alone, both or none (the last shape is
+    large enough for the staged upload of wide host arrays): the same result as the oracle, a float64 array
+    for host input, and the caller's arrays left as they were (the reference zeroes them in place)."""
+    import itertools
+
+    import torch
+
+    from hyperion_amd.score_norm import AdaptSNorm
+
+    ne, nt, nc, nbest, disc = shape
+    rng = np.random.RandomState(5)
+    S, CT, EC = rng.randn(ne, nt) * 3, rng.randn(nc, nt) * 3 + 1, rng.randn(ne, nc) * 3 - 1
+    mct, mec = rng.rand(nc, nt) > 0.2, rng.rand(ne, nc) > 0.2
+    for dt, use_ct, use_ec in itertools.product((np.float64, np.float32), (False, True), (False, True)):
+        host = [a.astype(dt) for a in (S, CT, EC)]
+        m1, m2 = (mct if use_ct else None), (mec if use_ec else None)
+        ref = O.adapt_s_norm(*[a.astype(np.float64) for a in host], nbest, disc, m1, m2)
+        for dev in (False, True):
+            args = [torch.from_numpy(a).cuda() for a in host] if dev else [a.copy() for a in host]
+            got = AdaptSNorm(nbest=nbest, nbest_discard=disc).predict(*args, mask_coh_test=m1, mask_enr_coh=m2)
+            for a, b in zip(args, host):
+                assert np.array_equal(a.cpu().numpy() if dev else a, b), "the caller's array was modified"
+            if dev:
+                got = got.cpu().numpy()
+            else:
+                assert got.dtype == np.float64
+            err = np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)
+            assert err.max() <= 2e-5, (dt.__name__, use_ct, use_ec, dev, err.max())
+
+
 def test_topk_ties_and_duplicates():
     """Exact ties: the selected set must have the right size and every selected value must be >=
     every unselected one; ties at the boundary go to the lower index."""

@@ -67,3 +67,34 @@ dev = [engine.upload(a) for a in (s_et, s_ec, np.ascontiguousarray(s_ct.T))]
 from hyperion_amd.score_norm.adapt_s_norm import adapt_s_norm_device  # noqa: E402
 t_dev, _ = wall(lambda: adapt_s_norm_device(dev[0], dev[1], dev[2], nbest, 0))
 print("  device tensors in/out (fp32):  %8.1f ms" % t_dev)
+
+# ---- the other host-array entry points at evaluation-set sizes ---------------------------------------
+from hyperion_amd.score_norm import SNorm  # noqa: E402
+from hyperion_amd.transforms import CentWhiten, LDA, LNorm, TransformList  # noqa: E402
+
+chain = synth.chain_cfg2(d=512, lda_dim=200)
+(_, mu_cw, T_cw), _, (_, mu_lda, T_lda) = chain
+pre = TransformList([CentWhiten(mu=mu_cw, T=T_cw), LNorm(), LDA(mu=mu_lda, T=T_lda)])
+xr = synth.raw_xvectors(100000, d=512, seed=5)[0]
+pre.predict(xr[:64])
+t_api, y = wall(lambda: pre.predict(xr))
+xd512 = engine.upload(xr)
+t_dev, _ = wall(lambda: pre.predict(xd512))
+print("TransformList.predict(numpy float64 100000 x 512 -> 200): %7.1f ms   device tensors %6.2f ms" % (t_api, t_dev))
+
+ids = np.repeat(np.arange(5000), 3)
+x_en = synth.length_norm(synth.sample_splda(m2, 5000, 3, 11))
+x_te = synth.length_norm(synth.sample_splda(m2, 20000, 1, 12))
+for method in ("vavg-lnorm", "savg", "book"):
+    p2.llr_Nvs1(x_en[:30], x_te[:8], ids1=ids[:30], method=method) if method != "book" else None
+    if method == "book":
+        D1 = p2.compute_stats_hard(x_en, ids)
+        D2 = p2.compute_stats_hard(x_te, np.arange(20000))
+        t_api, _ = wall(lambda: p2.llr_NvsM_book(D1, D2))
+    else:
+        t_api, _ = wall(lambda: p2.llr_Nvs1(x_en, x_te, ids1=ids, method=method))
+    print("llr_Nvs1 %-10s numpy 15000 segments of 5000 models x 20000: %7.1f ms" % (method, t_api))
+t_api, _ = wall(lambda: p2.llr_1vs1(xe, xt))
+print("llr_1vs1 numpy 2000 x 20000 (200-d):                         %7.1f ms" % t_api)
+t_api, _ = wall(lambda: SNorm().predict(s_et, s_ct, s_ec))
+print("SNorm.predict numpy 2000 x 20000, cohort 5000:                %7.1f ms" % t_api)
