@@ -225,7 +225,7 @@ class PLDABackend:
             exact = None
             if cohort.get("coh64") is not None and cohort.get("lazy"):
                 Gt_rows, Gt_cols, bt = T("prologue", lambda: self.plan.prologue_split_both(xc, bounds=True))
-                exact = dict(cohort["coh64"], bnd_rows=bt,
+                exact = dict(cohort["coh64"], bnd_rows=bt, defer=True,
                              rows64=lambda rows: self.plan.prologue_f64(_take64(x_test, c0, c1, rows), SIDE_ENROL))
             else:
                 Gt_rows, Gt_cols = T("prologue", lambda: self.plan.prologue_split_both(xc))
@@ -241,6 +241,10 @@ class PLDABackend:
                 e1 = min(ne, e0 + eb)
                 mt, it, ldt = T("gather_t", lambda: gather_stats(A_tc, None, e_idx[:, e0:e1], e1 - e0, 1e-5, k),
                                 (nq, e1 - e0, k))                                         # [chunk, enrol]
+                if exact is not None and "finish" in exact:
+                    # the tests' lists are first needed by the Z part: the host's wait for the number of rows
+                    # in doubt is spent behind the T part's launch
+                    T("topk_test", exact.pop("finish"))
                 S = T("score_trials", lambda: engine.score(_rows(Ge, e0, e1), Gt_cols))   # [enrol, chunk]
                 if reduce is None:
                     dst = out[e0:e1, c0:c1]

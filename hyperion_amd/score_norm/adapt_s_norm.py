@@ -16,7 +16,9 @@ def topk_rows(A, k, discard, exact=None):
     (fp64 packed rows, bounds) of just those rows, and "bnd_rows" from the fp32 prologue
     (Plan.prologue_split(..., bounds=True)): the fp64 rows are then made only for the few per cent of
     rows whose boundary has a second score inside its fp32 uncertainty band (one host read of their
-    count in between; the dict receives "redone" = that count).
+    count in between; the dict receives "redone" = that count).  With exact["defer"] = True that read and
+    the second selection are left to exact["finish"](), which the caller runs before it uses the lists:
+    work launched in between hides the host's wait.
     With exact["count"] = True the dict receives "counters" = (rows re-decided, rows skipped);
     exact["counters_dev"], a device int64[2], is added to instead and never read here (no host
     synchronisation: for callers that look at the totals once at the end)."""
@@ -62,17 +64,31 @@ def topk_rows(A, k, discard, exact=None):
     _lib.check(lib.hypmi_topk_rows(engine._ptr(A), n, nc, A.stride(0), k, discard, engine._ptr(idx),
                                    ldi, ex_ptr, engine._ptr(ws), ws_bytes, engine.stream_ptr()))
     if exact is not None and ex.mode == 3:
-        m = int(todo_count.item())  # rows that need exact values (waits for the selection above)
-        exact["redone"] = m
-        if m:
-            rows = torch.sort(todo[:m]).values
-            Gr, bnd_sub = exact["rows64"](rows)
-            assert Gr.shape[0] == m and Gr.shape[1] == Gc.shape[1] and Gr.stride(0) == Gc.stride(0)
-            assert bnd_sub.dtype == torch.float32 and tuple(bnd_sub.shape) == (m, 2) and bnd_sub.is_contiguous()
-            ex.mode, ex.G_rows, ex.bnd_rows, ex.row_map = 2, Gr.data_ptr(), bnd_sub.data_ptr(), rows.data_ptr()
-            ex.todo = ex.todo_count = None
-            _lib.check(lib.hypmi_topk_rows(engine._ptr(A), m, nc, A.stride(0), k, discard, engine._ptr(idx),
-                                           ldi, ctypes.byref(ex), engine._ptr(ws), ws_bytes, engine.stream_ptr()))
+        # the number of rows that need exact values travels to a page-locked word behind the selection;
+        # the host waits for that copy alone, not for what the caller may have launched after it
+        count_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        count_host.copy_(todo_count, non_blocking=True)
+        copied = torch.cuda.Event()
+        copied.record()
+
+        def finish():
+            copied.synchronize()
+            m = int(count_host[0])
+            exact["redone"] = m
+            if m:
+                rows = torch.sort(todo[:m]).values
+                Gr, bnd_sub = exact["rows64"](rows)
+                assert Gr.shape[0] == m and Gr.shape[1] == Gc.shape[1] and Gr.stride(0) == Gc.stride(0)
+                assert bnd_sub.dtype == torch.float32 and tuple(bnd_sub.shape) == (m, 2) and bnd_sub.is_contiguous()
+                ex.mode, ex.G_rows, ex.bnd_rows, ex.row_map = 2, Gr.data_ptr(), bnd_sub.data_ptr(), rows.data_ptr()
+                ex.todo = ex.todo_count = None
+                _lib.check(lib.hypmi_topk_rows(engine._ptr(A), m, nc, A.stride(0), k, discard, engine._ptr(idx),
+                                               ldi, ctypes.byref(ex), engine._ptr(ws), ws_bytes, engine.stream_ptr()))
+
+        if exact.get("defer"):
+            exact["finish"] = finish  # the caller runs it before the lists are used
+            return idx
+        finish()
     if counters is not None:
         exact["counters"] = tuple(int(v) for v in counters.cpu())
     return idx
