@@ -66,6 +66,9 @@ __global__ __launch_bounds__(1024) void valu_rate(float* out, int iters) {
 
 // ---------------------------------------------------------------- part 2: gather loops
 constexpr int GS = 1024;
+// shader clock (s_memtime) and constant 100 MHz clock (s_memrealtime) around the walk of one workgroup in the
+// middle of the grid: their ratio is the clock the chip holds under this load
+__device__ unsigned long long g_clk[4];
 
 // VAR 0: the shipped loop (per-list pivot, compiler-packed math)
 // VAR 1: pivot subtracted when the rows are copied to LDS; plain adds and fmas; and/bfe + lshl_add
@@ -168,6 +171,8 @@ __global__ __launch_bounds__(GS) void gather2(const float* __restrict__ X, int64
         p += ldi;
         if (++g_ld == G) { g_ld = 0; p += wrap; }
     }
+    const bool report = blockIdx.x == gridDim.x / 2 && tid == 0;
+    if (report) { g_clk[0] = clock64(); g_clk[1] = wall_clock64(); }
     float s1a = 0.f, s1b = 0.f, s2a = 0.f, s2b = 0.f;
     typedef float f4v __attribute__((ext_vector_type(4)));
     f4v ma = {0.f, 0.f, 0.f, 0.f}, mb = {0.f, 0.f, 0.f, 0.f};
@@ -229,6 +234,7 @@ __global__ __launch_bounds__(GS) void gather2(const float* __restrict__ X, int64
             }
         }
     }
+    if (report) { g_clk[2] = clock64(); g_clk[3] = wall_clock64(); }
 }
 
 // As gather2 (both moments) with list entries stored as 32-bit LDS byte offsets (four per 16-byte load):
@@ -410,6 +416,10 @@ int main(int argc, char** argv) {
         printf("  ring D=%d mode %d confine " #CF "  %8.3f ms  %6.2f elements/clk/CU  %5.2f clk per wave-entry per CU  index %5.2f TB/s\n", D, M, best, \
                el / (best * 1e-3) / ncu / (ghz * 1e9), 128.0 * ncu * ghz * 1e9 * best * 1e-3 / el,             \
                (rows / 2.0) * Q * kg * 16 / (best * 1e-3) / 1e12);                                             \
+        unsigned long long clk[4];                                                                             \
+        CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clk), sizeof(clk)));                                          \
+        printf("    shader clock under this load: %.0f MHz (walk of one workgroup: %.1f us)\n",                \
+               (double)(clk[2] - clk[0]) / ((double)(clk[3] - clk[1]) / 100.0), (double)(clk[3] - clk[1]) / 100.0); \
     }
         printf("pattern: %s (%d rows x %lld lists x %d)\n", pats[pat], rows, (long long)Q, k);
         GATHER(0)
