@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """What a 16-bit panel would cost the cohort-statistics gather in accuracy (host emulation, numpy only).
 
-The rows of both cohort panels are shifted by their row mean and stored as fp32, fp16 or bf16; the moments of
+The rows of both cohort panels are shifted by their row mean and stored as fp32, fp16, bf16 or 16-bit fixed point with a scale per row; the moments of
 every selection are then accumulated exactly, so that the only error is the storage format's.  Printed: the
 error of the normalised scores against the float64 oracle on a 300 x 600 slice of the default workload
 (chain + SPLDA, 20 000-member cohort, nbest 300), in the units of the 1e-4 parity bar.
@@ -31,7 +31,13 @@ def part(rows, sel_by, store):
     g = g.astype(np.float64)
     mu = g.mean(axis=2); var = (g * g).mean(axis=2) - mu * mu
     return piv + mu, np.sqrt(np.maximum(var, 0))
-for name, store in (("fp32", lambda a: a.astype(np.float32)), ("fp16", lambda a: a.astype(np.float16)),
+def int16_rows(a):
+    """Fixed point with one scale per row: the largest magnitude of the row maps to 32767."""
+    scale = np.abs(a).max(axis=1, keepdims=True) / 32767.0
+    return np.rint(a / scale) * scale
+
+
+for name, store in (("fp32", lambda a: a.astype(np.float32)), ("fp16", lambda a: a.astype(np.float16)), ("int16 per-row scale", int16_rows),
                     ("bf16", lambda a: (a.astype(np.float32).view(np.uint32) + 0x8000 & 0xffff0000).view(np.float32))):
     mz, sz = part(EC, CT.T, store)           # [ne, nt]
     mt, st = part(CT.T, EC, store)           # [nt, ne]
