@@ -189,11 +189,17 @@ def host_cpu():
     """(model name, threads numpy's BLAS uses) of the host the CPU baseline runs on."""
     model = "unknown"
     try:
+        fields = {}
         with open("/proc/cpuinfo") as f:
             for line in f:
-                if line.startswith("model name"):
-                    model = line.split(":", 1)[1].strip()
-                    break
+                if ":" in line:
+                    key, val = (t.strip() for t in line.split(":", 1))
+                    fields.setdefault(key, val)
+                if not line.strip():
+                    break  # first processor only
+        model = fields.get("model name", model)
+        if "cpu family" in fields:  # a virtual machine may hide the part number: family / model identify it
+            model += " (family %s model %s)" % (fields["cpu family"], fields.get("model", "?"))
     except OSError:
         pass
     try:
