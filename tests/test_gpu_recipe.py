@@ -72,3 +72,39 @@ def test_eval_be_snorm_script(tmp_path, monkeypatch, flow):
     want = ref[np.ix_(order_m, order_s)]
     # the text file keeps six decimals
     assert np.max(np.abs(got.scores - want) / np.maximum(np.abs(want), 1.0)) <= 1e-4 + 1e-6
+
+
+@pytest.mark.parametrize("pool", ["book", "vavg", "vavg-lnorm", "savg"])
+def test_eval_plda_script_n_vs_1(tmp_path, monkeypatch, pool):
+    """examples/eval_plda.py with multi-session models (19 enrolment segments of 10 models) into an HDF5 score
+    file, against the oracle's llr_Nvs1; and one block of the job grid."""
+    from hyperion_amd.utils.trial_scores import TrialScores
+
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import eval_plda
+
+    m, chain, _ = _files(tmp_path)
+    monkeypatch.chdir(DIR)
+    common = ["--iv-file", "scp:vectors.scp", "--ndx-file", "trials.ndx", "--enroll-file", "enroll.lst",
+              "--preproc-file", str(tmp_path / "pre.h5"), "--model-file", str(tmp_path / "plda.h5"),
+              "--plda-type", "splda", "--pool-method", pool, "-v", "0"]
+    out = str(tmp_path / "scores.h5")
+    eval_plda.main(common + ["--score-file", out])
+    g = np.load("expected.npz", allow_pickle=False)
+    ye = O.chain_predict(g["full_x_e"].astype(float), chain)
+    yt = O.chain_predict(g["full_x_t"].astype(float), chain)
+    models, ids = np.unique(g["full_info"], return_inverse=True)
+    ref = O.llr_Nvs1(m, ye, yt, ids1=ids, method=pool)
+    got = TrialScores.load(out)
+    assert list(got.model_set) == list(models) and list(got.seg_set) == list(g["full_seg_set"])
+    assert np.max(np.abs(got.scores - ref) / np.maximum(np.abs(ref), 1.0)) <= 1e-4
+    # block (2 of 3 models, 1 of 2 segments) of the job grid
+    part = str(tmp_path / "part.h5")
+    eval_plda.main(common + ["--score-file", part, "--model-part-idx", "2", "--num-model-parts", "3",
+                             "--seg-part-idx", "1", "--num-seg-parts", "2"])
+    blk = TrialScores.load(part)
+    assert list(blk.model_set) == list(g["part_2of3_1of2_model_set"])
+    assert list(blk.seg_set) == list(g["part_2of3_1of2_seg_set"])
+    rows = [list(got.model_set).index(x) for x in blk.model_set]
+    cols = [list(got.seg_set).index(x) for x in blk.seg_set]
+    assert np.allclose(blk.scores, got.scores[np.ix_(rows, cols)], rtol=0, atol=2e-5 * np.abs(got.scores).max())
