@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Stage times of the AS-norm pipeline with a given build of libhypmi.so, for A/B comparisons.
 
-    python tools/ab_lib.py <path to a libhypmi.so> [n_test]
+    python tools/ab_lib.py <path to a libhypmi.so> [n_test [nbest]]
 
 MI355X boxes differ by up to 12 % in every stage, so two builds are only comparable inside one job:
 build both libraries here, keep them side by side, and run this script once per library, alternating,
@@ -21,6 +21,8 @@ from hyperion_amd.transforms import LDA, CentWhiten, LNorm, TransformList  # noq
 
 cfg = dict(bench.WORKLOADS["asnorm_10k_128k"])
 cfg["n_test"] = int(sys.argv[2]) if len(sys.argv) > 2 else 196608
+if len(sys.argv) > 3:
+    cfg["nbest"] = int(sys.argv[3])
 chain, model = bench.build_workload(cfg)
 plda = SPLDA(mu=model["mu"], V=model["V"], W=model["W"])
 preproc = TransformList([CentWhiten(mu=chain[0][1], T=chain[0][2], name="cw"), LNorm(name="ln"),
