@@ -108,3 +108,48 @@ def test_eval_plda_script_n_vs_1(tmp_path, monkeypatch, pool):
     rows = [list(got.model_set).index(x) for x in blk.model_set]
     cols = [list(got.seg_set).index(x) for x in blk.seg_set]
     assert np.allclose(blk.scores, got.scores[np.ix_(rows, cols)], rtol=0, atol=2e-5 * np.abs(got.scores).max())
+
+
+def test_train_be_script_then_eval(tmp_path, monkeypatch):
+    """examples/train_be.py (egs/voxceleb/v1/steps_be/train-be-v1.py) writes the chain, the model and the ELBO
+    table; the chain and model it saves equal the same steps made by hand, and examples/eval_plda.py scores
+    with the files."""
+    from hyperion_amd.helpers import PLDAFactory, VectorClassReader
+    from hyperion_amd.transforms import LDA, LNorm, TransformList
+    from hyperion_amd.utils.trial_scores import TrialScores
+
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import eval_plda
+    import train_be
+
+    monkeypatch.chdir(DIR)
+    out = str(tmp_path / "be")
+    train_be.main(["--iv-file", "scp:vectors.scp", "--train-list", "train.utt2spk", "--lda-dim", "6",
+                   "--plda-type", "splda", "--y-dim", "3", "--epochs", "5", "--min-spc", "3",
+                   "--output-path", out, "-v", "0"])
+    elbo = np.loadtxt(out + "/elbo.csv", delimiter=",")
+    assert elbo.shape == (5, 3) and np.array_equal(elbo[:, 0], np.arange(5))
+    assert np.all(np.diff(elbo[:, 1]) > -1e-6 * abs(elbo[0, 1]))
+    # the same steps by hand
+    x, ids = VectorClassReader("scp:vectors.scp", "train.utt2spk", min_spc=3).read()
+    lda = LDA(lda_dim=6, name="lda")
+    lda.fit(x, ids)
+    lnorm = LNorm(name="lnorm")
+    lnorm.fit(lda.predict(x))
+    y = lnorm.predict(lda.predict(x))
+    plda = PLDAFactory.create_plda("splda", y_dim=3, name="plda")
+    ref_elbo, _ = plda.fit(y, ids, epochs=5)
+    assert np.allclose(elbo[:, 1], ref_elbo, rtol=1e-12)
+    pre = TransformList.load(out + "/lda_lnorm.h5")
+    assert np.allclose(pre.predict(x), y, rtol=1e-3, atol=1e-4)  # the files hold float32 parameters
+    scores = str(tmp_path / "scores.h5")
+    eval_plda.main(["--iv-file", "scp:vectors.scp", "--ndx-file", "trials.ndx", "--enroll-file", "enroll.lst",
+                    "--preproc-file", out + "/lda_lnorm.h5", "--model-file", out + "/plda.h5", "--plda-type",
+                    "splda", "--pool-method", "vavg-lnorm", "--score-file", scores, "-v", "0"])
+    got = TrialScores.load(scores)
+    g = np.load("expected.npz", allow_pickle=False)
+    models, mid = np.unique(g["full_info"], return_inverse=True)
+    want = plda.llr_Nvs1(lnorm.predict(lda.predict(g["full_x_e"].astype(float))),
+                         lnorm.predict(lda.predict(g["full_x_t"].astype(float))), ids1=mid, method="vavg-lnorm")
+    assert got.scores.shape == want.shape
+    assert np.allclose(got.scores, want, rtol=2e-3, atol=2e-3)
