@@ -59,11 +59,12 @@ def upload(x, dtype=None):
         raise ValueError("expected a 2-D array of embeddings, got shape %s" % (x.shape,))
     n, d = x.shape
     ld = round_up(d, 4)
-    if ld == d and x.dtype != np.float32 and x.size >= (1 << 20) and x.flags.c_contiguous:
+    if (ld == d and x.dtype != np.float32 and x.size >= (1 << 20) and x.flags.c_contiguous
+            and x.dtype.isnative and x.dtype.kind == "f" and x.dtype.itemsize in (2, 8)):
         # a wide host type: narrowed by torch's threaded copy into a page-locked buffer and sent from
         # there (numpy's serial astype plus a pageable copy take four times as long)
         stage = _pinned("up32", x.size, torch.float32)[:x.size].view(n, d)
-        stage.copy_(torch.from_numpy(x))
+        stage.copy_(_as_tensor(x))
         t = stage.to(device="cuda", non_blocking=True)
         torch.cuda.current_stream().synchronize()  # the buffer is reused by the next call
         return t
@@ -87,10 +88,20 @@ def upload64(x):
     if x.size < (1 << 20):
         return torch.from_numpy(x).cuda()
     stage = _pinned("up64", x.size, torch.float64)[:x.size].view(x.shape)
-    stage.copy_(torch.from_numpy(x))
+    stage.copy_(_as_tensor(x))
     t = stage.to(device="cuda", non_blocking=True)
     torch.cuda.current_stream().synchronize()  # the buffer is reused by the next call
     return t
+
+
+def _as_tensor(x):
+    """torch view of a host array that is only read (a read-only array would draw torch's warning
+    about writes through the view)."""
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        return _torch().from_numpy(x)
 
 
 def _pinned(key, numel, dtype):
