@@ -1110,3 +1110,40 @@ def test_gather_stats_two_close_members_far_from_the_row_mean():
     s_ref = np.maximum(sel.std(axis=2), 1e-5)
     assert np.max(np.abs(istd[:, :lists].cpu().numpy() * s_ref - 1.0)) <= 2e-6
     assert np.max(np.abs(mean[:, :lists].cpu().numpy() - sel.mean(axis=2))) <= 4e-6 * 60
+
+
+def test_two_host_threads_with_their_own_models_and_streams():
+    """Two Python threads, each with its own model object (its own plan and workspaces) and its own
+    stream, score and normalise at the same time through the host-array API: the same results as one thread
+    alone (staging buffers and the error string are per thread, plans are not shared)."""
+    import threading
+
+    import synth
+    import torch
+
+    from hyperion_amd.score_norm import AdaptSNorm
+
+    m = synth.make_splda(64, 20)
+    x = [synth.length_norm(synth.sample_splda(m, n, 1, seed)) for n, seed in ((700, 1), (1600, 2), (900, 3))]
+    alone = make("splda", m)
+    ref_s = alone.llr_1vs1(x[0], x[1])
+    ref_n = AdaptSNorm(nbest=50).predict(ref_s, alone.llr_1vs1(x[2], x[1]), alone.llr_1vs1(x[0], x[2]))
+    errors = []
+
+    def work():
+        try:
+            plda = make("splda", m)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(6):
+                    s = plda.llr_1vs1(x[0], x[1])
+                    n = AdaptSNorm(nbest=50).predict(s, plda.llr_1vs1(x[2], x[1]), plda.llr_1vs1(x[0], x[2]))
+                    assert np.array_equal(s, ref_s) and np.array_equal(n, ref_n)
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work) for _ in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
