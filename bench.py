@@ -65,6 +65,8 @@ def parse(argv=None):
                     help="rows/cols of the square slice the raw-score CPU baseline is timed on")
     ap.add_argument("--split-format", default="pair", choices=["pair", "triple", "none"],
                     help="operands of the score kernel: scaled fp16 pairs, exact bf16 triples, or fp32")
+    ap.add_argument("--test-chunk", type=int, default=None,
+                    help="tests per chunk of the AS-norm pipeline (default: the workload's own, else 65536)")
     ap.add_argument("--dry-run", action="store_true",
                     help="start the ranks, form the process group, exchange one number, print the rank "
                          "count and stop (no GPU work): a check of the launch path")
@@ -644,7 +646,9 @@ def main():
     from hyperion_amd.pdfs.plda import SPLDA
     from hyperion_amd.transforms import LDA, CentWhiten, LNorm, TransformList
 
-    cfg = WORKLOADS[args.workload]
+    cfg = dict(WORKLOADS[args.workload])
+    if args.test_chunk:
+        cfg["test_chunk"] = args.test_chunk
     chain, model = build_workload(cfg)
     plda = SPLDA(mu=model["mu"], V=model["V"], W=model["W"])
     preproc = None
