@@ -130,6 +130,11 @@ SIGNATURES = {
     "hypmi_gather_apply": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, i64, c_void_p, i64, ctypes.c_int, i64,
                                           ctypes.c_float, c_void_p, i64, c_void_p, c_void_p, i64, c_void_p, i64,
                                           c_void_p]),
+    "hypmi_gather_stats_pairs": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, i64, c_void_p, i64, ctypes.c_int, i64,
+                                                ctypes.c_float, c_void_p, i64, c_void_p]),
+    "hypmi_gather_apply_pairs": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, i64, c_void_p, i64, ctypes.c_int, i64,
+                                                ctypes.c_float, c_void_p, i64, c_void_p, i64, c_void_p, i64,
+                                                c_void_p]),
     "hypmi_gather_redo_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
     "hypmi_asnorm_apply": (ctypes.c_int, [c_void_p, i64, i64, i64, c_void_p, c_void_p, i64, c_void_p,
                                           c_void_p, i64, c_void_p, i64, c_void_p]),

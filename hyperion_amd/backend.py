@@ -15,7 +15,8 @@ import numpy as np
 
 from . import engine
 from .engine import SIDE_ENROL, SIDE_TEST
-from .score_norm.adapt_s_norm import gather_apply, gather_apply_supported, gather_stats, topk_rows
+from .score_norm.adapt_s_norm import (gather_apply, gather_apply_pairs, gather_apply_supported, gather_stats,
+                                      gather_stats_pairs, topk_rows)
 
 
 def shard_range(n, part, num_parts):
@@ -95,6 +96,7 @@ class PLDABackend:
         self.tile_bytes = 96 << 30
         # finish the normalisation inside the Z-part statistics kernel (no separate apply pass)
         self.fuse_apply = True
+        self.pair_stats = True  # fused path: T-part mean and 1 / std side by side (one line per list in the Z part)
         # float64 rows for the exact top-k only where a boundary is in doubt (False: for every vector)
         self.lazy_exact = True
         # re-decide top-k members that fp32 cannot separate from the selection boundary with fp64
@@ -239,8 +241,14 @@ class PLDABackend:
             nq = c1 - c0
             for e0 in range(0, ne, eb):
                 e1 = min(ne, e0 + eb)
-                mt, it, ldt = T("gather_t", lambda: gather_stats(A_tc, None, e_idx[:, e0:e1], e1 - e0, 1e-5, k),
-                                (nq, e1 - e0, k))                                         # [chunk, enrol]
+                paired = fused and self.pair_stats
+                if paired:
+                    mt, ldt = T("gather_t", lambda: gather_stats_pairs(A_tc, e_idx[:, e0:e1], e1 - e0, 1e-5, k),
+                                (nq, e1 - e0, k))                                         # [chunk, enrol, 2]
+                    it = None
+                else:
+                    mt, it, ldt = T("gather_t", lambda: gather_stats(A_tc, None, e_idx[:, e0:e1], e1 - e0, 1e-5, k),
+                                    (nq, e1 - e0, k))                                     # [chunk, enrol]
                 if exact is not None and "finish" in exact:
                     # the tests' lists are first needed by the Z part: the host's wait for the number of rows
                     # in doubt is spent behind the T part's launch
@@ -251,7 +259,10 @@ class PLDABackend:
                 else:
                     dst = torch.empty((e1 - e0, engine.round_up(nq, 32)), dtype=torch.float32,
                                       device=xt.device)[:, :nq]
-                if fused:
+                if paired:
+                    T("gather_z", lambda: gather_apply_pairs(A_ec[e0:e1], t_idx, nq, 1e-5, k, S, mt, ldt, dst),
+                      (e1 - e0, nq, k))
+                elif fused:
                     # Z-part statistics and the normalisation in one launch: the statistics never leave
                     # the registers
                     T("gather_z", lambda: gather_apply(A_ec[e0:e1], t_idx, nq, 1e-5, k, S, mt, it, ldt, dst),

@@ -1021,6 +1021,7 @@ constexpr int GP_XCD_GROUPS = 16;  // row groups that share 128-byte lines of th
 // one rounding per operation in this order wherever it is computed (no contraction into fma), so that
 // the fused and the separate paths give the same bits.
 __device__ __forceinline__ float asnorm_value(float s, float mz, float iz, float mt, float it) {
+#pragma clang fp contract(off)  // __fmul_rn / __fadd_rn are plain operators here and would fuse into z + (s - mt) it
     const float z = __fmul_rn(__fsub_rn(s, mz), iz);
     const float t = __fmul_rn(__fsub_rn(s, mt), it);
     return __fmul_rn(__fadd_rn(z, t), 0.70710678118654752440f);
@@ -1060,6 +1061,23 @@ template <int R>
 __device__ __forceinline__ float lds_vec_elem(const typename LdsVec<R>::type& v, int rr) { return v[rr]; }
 template <>
 __device__ __forceinline__ float lds_vec_elem<1>(const float& v, int) { return v; }
+
+// R (mean, 1 / std) pairs from global memory, 8 R bytes at an address that is a multiple of min(8 R, 16)
+template <int R>
+__device__ __forceinline__ typename LdsVec<2 * R>::type load_pairs(const float* p) {
+    typename LdsVec<2 * R>::type v;
+    if constexpr (R == 1) {
+        const float2 a = *reinterpret_cast<const float2*>(p);
+        v[0] = a.x; v[1] = a.y;
+    } else {
+#pragma unroll
+        for (int h = 0; h < R / 2; ++h) {
+            const float4 a = *reinterpret_cast<const float4*>(p + 4 * h);
+            v[4 * h] = a.x; v[4 * h + 1] = a.y; v[4 * h + 2] = a.z; v[4 * h + 3] = a.w;
+        }
+    }
+    return v;
+}
 
 __device__ __forceinline__ unsigned lds_address(const void* p) {
     return (unsigned)reinterpret_cast<size_t>((__attribute__((address_space(3))) const void*)p);
@@ -1134,11 +1152,16 @@ __device__ __forceinline__ void rotate_priority(int turn) {
     }
 }
 
-template <int R, bool APPLY>
+// MODE 0: (mean, 1 / std) stored, in two arrays or -- istd == nullptr -- as pairs in one ([rows, ldo] pairs);
+// 1: APPLY with the other side's statistics in two arrays; 2: APPLY with them as pairs ([lists, ldt] pairs: one
+// load of 8 R bytes per lane and list instead of two of 4 R -- a lane's load is a line of its own, and
+// every such line costs the CU about a clock of its vector-memory path that the walk cannot use).
+template <int R, int MODE>
 __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
     const float* __restrict__ X, int64_t ldx, int64_t n_rows, int nc, const uint16_t* __restrict__ idx8,
     int64_t ldi, int k, int64_t Q, int64_t q_per_block, float floor_, float* __restrict__ mean,
     float* __restrict__ istd, int64_t ldo, ApplyArgs ap) {
+    constexpr bool APPLY = MODE != 0, PAIRS = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) float xr[];
     float* red = xr + (size_t)nc * R;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1294,13 +1317,18 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
     // requests of the sixteen waves (which reach the ends of their lists together) have a whole list's
     // walk to drain instead of stalling everyone at once.
     typename LdsVec<R>::type pm, pi;
+    typename LdsVec<2 * R>::type pmi;  // PAIRS: (mean, 1 / std) of row 0, of row 1, ...
     float ps[R];
 #define HYPMI_APPLY_PREFETCH(LIST)                                                                  \
     if (APPLY) {                                                                                    \
         int64_t qq = q0 + tid + (int64_t)(LIST) * GS_THREADS;                                       \
         qq = qq < q1 ? qq : q1 - 1;                                                                 \
-        pm = *reinterpret_cast<const typename LdsVec<R>::type*>(ap.mt + qq * ap.ldt + r0);          \
-        pi = *reinterpret_cast<const typename LdsVec<R>::type*>(ap.it + qq * ap.ldt + r0);          \
+        if (PAIRS) {                                                                                \
+            pmi = load_pairs<R>(ap.mt + (qq * ap.ldt + r0) * 2);                                    \
+        } else {                                                                                    \
+            pm = *reinterpret_cast<const typename LdsVec<R>::type*>(ap.mt + qq * ap.ldt + r0);      \
+            pi = *reinterpret_cast<const typename LdsVec<R>::type*>(ap.it + qq * ap.ldt + r0);      \
+        }                                                                                           \
         _Pragma("unroll") for (int rr = 0; rr < R; ++rr) {                                          \
             const int64_t e = r0 + rr < n_rows ? r0 + rr : n_rows - 1;                              \
             ps[rr] = __builtin_nontemporal_load(ap.S + e * ap.lds + qq);                            \
@@ -1372,10 +1400,16 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
                 /* 1 / max(sqrt(var), floor): v_rsq_f32 is good to one unit in the last place */                \
                 const float is = var < floor2 ? inv_floor : __builtin_amdgcn_rsqf(var);                         \
                 if (live_q && r0 + rr < n_rows) {                                                               \
-                    const float m = lp[rr] + md;                                                                \
-                    if (APPLY) {                                                                                \
+                    /* one explicit fma: left as `lp + md` the compiler contracts it in some variants of the    \
+                       kernel and not in others (__fadd_rn is a plain `+` here), and they are compared bit for bit */ \
+                    const float m = fmaf(s1[rr], inv_k, lp[rr]);                                                \
+                    if (PAIRS) {                                                                                \
+                        ap.out[(r0 + rr) * ap.ldo + q] = asnorm_value(ps[rr], m, is, pmi[2 * rr], pmi[2 * rr + 1]); \
+                    } else if (APPLY) {                                                                         \
                         ap.out[(r0 + rr) * ap.ldo + q] =                                                        \
                             asnorm_value(ps[rr], m, is, lds_vec_elem<R>(pm, rr), lds_vec_elem<R>(pi, rr));      \
+                    } else if (istd == nullptr) {                                                               \
+                        reinterpret_cast<float2*>(mean)[(r0 + rr) * ldo + q] = make_float2(m, is);              \
                     } else {                                                                                    \
                         mean[(r0 + rr) * ldo + q] = m;                                                          \
                         istd[(r0 + rr) * ldo + q] = is;                                                         \
@@ -1640,22 +1674,22 @@ inline int64_t pivot_lds_bytes(int nc, int R) {
     return round_up(((int64_t)nc * R + GP_SCRATCH_FLOATS) * 4, 16);
 }
 
-template <int R, bool APPLY = false>
+template <int R, int MODE = 0>
 int launch_gather_pivot(const float* X, int64_t n_rows, int nc, int64_t ldx, const uint16_t* idx8, int64_t ldi,
                         int k, int64_t n_lists, float std_floor, float* mean, float* istd, int64_t ldo,
                         hipStream_t stream, const ApplyArgs& ap = ApplyArgs{}) {
     const int64_t lds_need = pivot_lds_bytes(nc, R);
     if (lds_need > 48 * 1024)
-        HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_pivot_kernel<R, APPLY>),
+        HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_pivot_kernel<R, MODE>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
     const int64_t groups = (n_rows + R - 1) / R;
     int64_t chunks, q_per_block;
     gather_grid(groups, n_lists, &chunks, &q_per_block);
     // with APPLY the row groups are renumbered in sets of 8 x GP_XCD_GROUPS: pad the grid to whole sets
-    const int64_t gx = APPLY ? round_up(groups, 8 * GP_XCD_GROUPS) : groups;
+    const int64_t gx = MODE != 0 ? round_up(groups, 8 * GP_XCD_GROUPS) : groups;
     HYPMI_REQUIRE(gx <= 0x7fffffffLL, "gather_stats: too many rows");
     HYPMI_REQUIRE((q_per_block / GS_THREADS) * ((k + 7) / 8) < 0x7fffffffLL, "gather_stats: lists too long");
-    hipLaunchKernelGGL((gather_pivot_kernel<R, APPLY>), dim3((unsigned)gx, (unsigned)chunks), dim3(GS_THREADS),
+    hipLaunchKernelGGL((gather_pivot_kernel<R, MODE>), dim3((unsigned)gx, (unsigned)chunks), dim3(GS_THREADS),
                        lds_need, stream, X, ldx, n_rows, nc, idx8, ldi, k, n_lists, q_per_block, std_floor, mean,
                        istd, ldo, ap);
     HYPMI_HIP(hipGetLastError());
@@ -1741,13 +1775,62 @@ extern "C" int hypmi_gather_apply(const float* X, int64_t n_rows, int nc, int64_
                   "the rows rounded up to it) and %d-byte alignment", R, 4 * R);
     const ApplyArgs ap = {S, lds_, mt, it, ldt, out, ldo};
     if (R == 4)
-        return launch_gather_pivot<4, true>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, nullptr, nullptr,
+        return launch_gather_pivot<4, 1>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, nullptr, nullptr,
                                             0, stream, ap);
     if (R == 2)
-        return launch_gather_pivot<2, true>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, nullptr, nullptr,
+        return launch_gather_pivot<2, 1>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, nullptr, nullptr,
                                             0, stream, ap);
-    return launch_gather_pivot<1, true>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, nullptr, nullptr, 0,
+    return launch_gather_pivot<1, 1>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, nullptr, nullptr, 0,
                                         stream, ap);
+}
+
+extern "C" int hypmi_gather_stats_pairs(const float* X, int64_t n_rows, int nc, int64_t ldx, const uint16_t* idx_t,
+                                        int64_t ldi, int k, int64_t n_lists, float std_floor, float* stats,
+                                        int64_t ldo, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HYPMI_REQUIRE(X && idx_t && stats, "gather_stats_pairs: null pointer");
+    HYPMI_REQUIRE(n_rows >= 0 && nc > 0 && nc <= 65536 && ldx >= nc && k > 0 && n_lists >= 0 && ldi >= n_lists &&
+                      ldo >= n_lists,
+                  "gather_stats_pairs: bad shape");
+    HYPMI_REQUIRE(aligned16(idx_t), "gather_stats_pairs: index lists must be 16-byte aligned");
+    HYPMI_REQUIRE(reinterpret_cast<uintptr_t>(stats) % 8 == 0, "gather_stats_pairs: statistics must be 8-byte aligned");
+    if (n_rows == 0 || n_lists == 0) return HYPMI_OK;
+    const int R = pivot_rows_per_group(nc, n_rows);
+    HYPMI_REQUIRE(R != 0, "gather_stats_pairs: a cohort of %d does not fit in LDS (use gather_stats)", nc);
+    if (R == 4)
+        return launch_gather_pivot<4>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, stats, nullptr, ldo, stream);
+    if (R == 2)
+        return launch_gather_pivot<2>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, stats, nullptr, ldo, stream);
+    return launch_gather_pivot<1>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, stats, nullptr, ldo, stream);
+}
+
+extern "C" int hypmi_gather_apply_pairs(const float* X, int64_t n_rows, int nc, int64_t ldx, const uint16_t* idx_t,
+                                        int64_t ldi, int k, int64_t n_lists, float std_floor, const float* S,
+                                        int64_t lds_, const float* stats_t, int64_t ldt, float* out, int64_t ldo,
+                                        void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HYPMI_REQUIRE(X && idx_t && S && stats_t && out, "gather_apply_pairs: null pointer");
+    HYPMI_REQUIRE(n_rows >= 0 && nc > 0 && nc <= 65536 && ldx >= nc && k > 0 && n_lists >= 0 && ldi >= n_lists &&
+                      lds_ >= n_lists && ldo >= n_lists && ldt >= n_rows,
+                  "gather_apply_pairs: bad shape");
+    HYPMI_REQUIRE(aligned16(idx_t), "gather_apply_pairs: index lists must be 16-byte aligned");
+    if (n_rows == 0 || n_lists == 0) return HYPMI_OK;
+    const int R = pivot_rows_per_group(nc, n_rows);
+    HYPMI_REQUIRE(R != 0, "gather_apply_pairs: a cohort of %d does not fit in LDS (use gather_stats + asnorm_apply)", nc);
+    // the R pairs of a row group are read with one load (two of 16 bytes for four rows)
+    HYPMI_REQUIRE(ldt % R == 0 && ldt >= round_up(n_rows, R) &&
+                      reinterpret_cast<uintptr_t>(stats_t) % (R == 4 ? 16 : 8 * R) == 0,
+                  "gather_apply_pairs: T-part statistics need a leading dimension (in pairs) that is a multiple of "
+                  "%d (and covers the rows rounded up to it) and %d-byte alignment", R, R == 4 ? 16 : 8 * R);
+    const ApplyArgs ap = {S, lds_, stats_t, nullptr, ldt, out, ldo};
+    if (R == 4)
+        return launch_gather_pivot<4, 2>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, nullptr, nullptr, 0,
+                                         stream, ap);
+    if (R == 2)
+        return launch_gather_pivot<2, 2>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, nullptr, nullptr, 0,
+                                         stream, ap);
+    return launch_gather_pivot<1, 2>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, nullptr, nullptr, 0,
+                                     stream, ap);
 }
 
 extern "C" int hypmi_gather_redo_count(unsigned long long* count, int reset) {

@@ -121,6 +121,35 @@ def gather_stats(X, mask_u8, idx, n_lists, std_floor, k):
     return mean, istd, ld
 
 
+def gather_stats_pairs(X, idx, n_lists, std_floor, k):
+    """gather_stats (unmasked, rows that fit in LDS) with mean and inverse std of a (row, list) side by side:
+    one device array [rows, ld, 2] and ld (in pairs)."""
+    torch = engine.require_gpu()
+    n, nc = X.shape
+    assert idx.stride(2) == 1 and idx.stride(1) == 8 and idx.shape[1] >= n_lists
+    ld = engine.round_up(max(n_lists, 1), 4)
+    if ld % 256 == 0:
+        ld += 16  # read down its columns as well: no stride that maps a column to one memory channel
+    stats = torch.empty((n, ld, 2), dtype=torch.float32, device=X.device)
+    _lib.check(_lib.load().hypmi_gather_stats_pairs(engine._ptr(X), n, nc, X.stride(0), engine._ptr(idx),
+                                                    idx.stride(0) // 8, int(k), n_lists, float(std_floor),
+                                                    engine._ptr(stats), ld, engine.stream_ptr()))
+    return stats, ld
+
+
+def gather_apply_pairs(X, idx, n_lists, std_floor, k, S, stats_t, ldt, out):
+    """gather_apply with the T-part statistics as the pairs gather_stats_pairs makes ([test, ldt, 2])."""
+    n, nc = X.shape
+    assert idx.stride(2) == 1 and idx.stride(1) == 8 and idx.shape[1] >= n_lists
+    assert S.shape[0] == n and S.shape[1] >= n_lists and out.shape[0] == n and out.shape[1] >= n_lists
+    assert stats_t.shape[0] >= n_lists and ldt >= n
+    _lib.check(_lib.load().hypmi_gather_apply_pairs(engine._ptr(X), n, nc, X.stride(0), engine._ptr(idx),
+                                                    idx.stride(0) // 8, int(k), n_lists, float(std_floor),
+                                                    engine._ptr(S), S.stride(0), engine._ptr(stats_t), ldt,
+                                                    engine._ptr(out), out.stride(0), engine.stream_ptr()))
+    return out
+
+
 def gather_apply_supported(nc, n_rows):
     """Whether gather_apply can run for a cohort of nc members (its rows have to fit in LDS)."""
     return bool(_lib.load().hypmi_gather_apply_supported(int(nc), int(n_rows)))

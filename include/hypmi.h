@@ -329,6 +329,20 @@ int hypmi_gather_apply(const float* X, int64_t n_rows, int nc, int64_t ldx, cons
                        int k, int64_t n_lists, float std_floor, const float* S, int64_t lds, const float* mt,
                        const float* it, int64_t ldt, float* out, int64_t ldo, void* stream);
 
+/* The same two steps with the T-part statistics as (mean, 1 / std) PAIRS in one array instead of two
+ * arrays: hypmi_gather_stats_pairs writes stats[(r ldo + q) 2 + {0, 1}] (ldo counted in pairs; unmasked
+ * rows that fit in LDS only, hypmi_gather_apply_supported(nc, n_rows) tells), hypmi_gather_apply_pairs
+ * reads them as stats_t[(q ldt + r) 2 + {0, 1}] (adapt_s_norm.py:69-86, then 46-63 and 88).  Same bits
+ * as the calls above.  A lane of hypmi_gather_apply reads the statistics of its list from a memory line
+ * of its own; with pairs it touches one such line per list instead of two, which is worth 3 % of the
+ * launch. */
+int hypmi_gather_stats_pairs(const float* X, int64_t n_rows, int nc, int64_t ldx, const uint16_t* idx,
+                             int64_t ldi, int k, int64_t n_lists, float std_floor, float* stats, int64_t ldo,
+                             void* stream);
+int hypmi_gather_apply_pairs(const float* X, int64_t n_rows, int nc, int64_t ldx, const uint16_t* idx,
+                             int64_t ldi, int k, int64_t n_lists, float std_floor, const float* S, int64_t lds,
+                             const float* stats_t, int64_t ldt, float* out, int64_t ldo, void* stream);
+
 /* X[i,j] = 0 where mask[i,j] == 0: `scores[mask == False] = 0` (adapt_s_norm.py:37-40,
  * t_norm.py:21, z_norm.py:22), applied to the library's device copy, never to caller arrays. */
 int hypmi_mask_zero(float* X, int64_t rows, int64_t cols, int64_t ldx, const unsigned char* mask,

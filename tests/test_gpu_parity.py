@@ -1016,6 +1016,15 @@ def test_gather_apply_equals_gather_then_apply(ne, nt, nc, k):
     gather_apply(A_ec, t_idx, nt, 1e-5, k, S, mt, it, ldt, out)
     assert torch.equal(out, ref)  # including the untouched padding columns
     assert not gather_apply_supported(45_000, ne)
+    # the same two steps with mean and 1 / std of a (test, model) pair side by side in one array
+    from hyperion_amd.score_norm.adapt_s_norm import gather_apply_pairs, gather_stats_pairs
+
+    st, ldp = gather_stats_pairs(A_tc, e_idx, ne, 1e-5, k)
+    assert st.shape == (nt, ldp, 2)
+    assert torch.equal(st[:, :ne, 0], mt[:, :ne]) and torch.equal(st[:, :ne, 1], it[:, :ne])
+    out2 = torch.full((ne, ld), 7.0, dtype=torch.float32, device="cuda")
+    gather_apply_pairs(A_ec, t_idx, nt, 1e-5, k, S, st, ldp, out2)
+    assert torch.equal(out2, ref)
 
 
 @pytest.mark.gpu

@@ -27,6 +27,16 @@ chain, model = bench.build_workload(cfg)
 plda = SPLDA(mu=model["mu"], V=model["V"], W=model["W"])
 preproc = TransformList([CentWhiten(mu=chain[0][1], T=chain[0][2], name="cw"), LNorm(name="ln"),
                          LDA(mu=chain[2][1], T=chain[2][2], name="lda")])
+if os.environ.get("HYPMI_PAIR_STATS") == "0":  # the T-part statistics in two arrays, as before the paired layout
+    from hyperion_amd.backend import PLDABackend
+
+    _init = PLDABackend.__init__
+
+    def _init_unpaired(self, *a, **kw):
+        _init(self, *a, **kw)
+        self.pair_stats = False
+
+    PLDABackend.__init__ = _init_unpaired
 dt, st, be, bufs = bench.asnorm_run(plda, preproc, cfg, 4, 2, 0, 1, None)
 print(os.path.basename(sys.argv[1]), "ms/step %.1f" % (dt * 1e3),
       {k: round(x, 1) for k, x in st["per_step_ms"].items()}, flush=True)
