@@ -189,8 +189,13 @@ def adapt_s_norm_device(S, A_ec, A_tc, nbest, nbest_discard, mask_ec=None, mask_
         return out[:, :nt]
     t_idx = topk_rows(A_tc, k, int(nbest_discard), exact_tc)  # per test: cohort ranked by coh-vs-test
     e_idx = topk_rows(A_ec, k, int(nbest_discard), exact_ec)  # per enrol: cohort ranked by enr-vs-coh
+    fused = mask_ec is None and gather_apply_supported(nc, ne)
+    if fused and mask_tc is None:  # T-part mean and 1 / std side by side: one line per list in the Z part
+        st, ldt = gather_stats_pairs(A_tc, e_idx, ne, std_floor, k)  # [test, enrol, 2]
+        gather_apply_pairs(A_ec, t_idx, nt, std_floor, k, S, st, ldt, out)
+        return out[:, :nt]
     mt, it, ldt = gather_stats(A_tc, mask_tc, e_idx, ne, std_floor, k)  # [test, enrol]
-    if mask_ec is None and gather_apply_supported(nc, ne):
+    if fused:
         gather_apply(A_ec, t_idx, nt, std_floor, k, S, mt, it, ldt, out)
         return out[:, :nt]
     mz, iz, ldz = gather_stats(A_ec, mask_ec, t_idx, nt, std_floor, k)  # [enrol, test]
