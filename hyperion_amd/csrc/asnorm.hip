@@ -1638,11 +1638,14 @@ extern "C" int hypmi_topk_rows(const float* A, int64_t n_rows, int nc, int64_t l
 }
 
 namespace {
-// One workgroup walks all lists for its rows unless there are too few row groups to fill the chip, in
-// which case the lists are split over blockIdx.y (every block of lists reloads the rows, so blocks
-// are kept as large as that allows).
+// One workgroup walks up to 64 rounds of lists for its rows: the index lists of a block (600 bytes each
+// at 300 members) are read by every row group, and beyond about 40 MB they no longer stay in the caches
+// the row groups share (262 144 lists in one block: the launch took 1.45 times as long per list).  With
+// too few row groups to fill the chip the lists are split further over blockIdx.y (every block of lists
+// reloads the rows, so blocks are kept as large as that allows).
 inline void gather_grid(int64_t groups, int64_t n_lists, int64_t* chunks_out, int64_t* q_per_block_out) {
-    int64_t chunks = 1;
+    int64_t chunks = (n_lists + 64 * GS_THREADS - 1) / (64 * GS_THREADS);
+    if (chunks < 1) chunks = 1;
     while (groups * chunks < 1024 && (n_lists + chunks - 1) / chunks > 4 * GS_THREADS) chunks *= 2;
     if (chunks > 65535) chunks = 65535;
     const int64_t q_per_block = round_up((n_lists + chunks - 1) / chunks, GS_THREADS);
