@@ -241,6 +241,9 @@ class PLDABackend:
             nq = c1 - c0
             for e0 in range(0, ne, eb):
                 e1 = min(ne, e0 + eb)
+                # the trial scores before the two gathers: the score kernel pulls the clock down, and a gather
+                # that starts behind it runs its first half millisecond at that clock
+                S = T("score_trials", lambda: engine.score(_rows(Ge, e0, e1), Gt_cols))   # [enrol, chunk]
                 paired = fused and self.pair_stats
                 if paired:
                     mt, ldt = T("gather_t", lambda: gather_stats_pairs(A_tc, e_idx[:, e0:e1], e1 - e0, 1e-5, k),
@@ -253,7 +256,6 @@ class PLDABackend:
                     # the tests' lists are first needed by the Z part: the host's wait for the number of rows
                     # in doubt is spent behind the T part's launch
                     T("topk_test", exact.pop("finish"))
-                S = T("score_trials", lambda: engine.score(_rows(Ge, e0, e1), Gt_cols))   # [enrol, chunk]
                 if reduce is None:
                     dst = out[e0:e1, c0:c1]
                 else:
