@@ -11,6 +11,11 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
+from hyperion_amd import _lib  # noqa: E402
+
+if len(sys.argv) > 1:  # another build of the library (A/B comparisons inside one GPU call)
+    _lib.LIB_PATH = os.path.abspath(sys.argv[1])
+
 from hyperion_amd.score_norm.adapt_s_norm import gather_stats, topk_rows  # noqa: E402
 
 torch.manual_seed(0)
