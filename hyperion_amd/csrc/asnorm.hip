@@ -1638,13 +1638,17 @@ extern "C" int hypmi_topk_rows(const float* A, int64_t n_rows, int nc, int64_t l
 }
 
 namespace {
-// One workgroup walks up to 64 rounds of lists for its rows: the index lists of a block (600 bytes each
-// at 300 members) are read by every row group, and beyond about 40 MB they no longer stay in the caches
-// the row groups share (262 144 lists in one block: the launch took 1.45 times as long per list).  With
+// One workgroup walks up to max_rounds rounds of lists for its rows: the index lists of a block (600 bytes
+// each at 300 members) are read by every row group, and when they are too many they no longer stay in the
+// caches the row groups share (262 144 lists in one block: the launch took 1.45 times as long per list).
+// 128 rounds (79 MB of lists) run at the rate of 64 in the plain kernel and pay the row fill half as often;
+// the kernel that also normalises, whose loads of scores and statistics share those caches, is 1 %
+// faster with 64 (both builds alternating on one GPU).  With
 // too few row groups to fill the chip the lists are split further over blockIdx.y (every block of lists
 // reloads the rows, so blocks are kept as large as that allows).
-inline void gather_grid(int64_t groups, int64_t n_lists, int64_t* chunks_out, int64_t* q_per_block_out) {
-    int64_t chunks = (n_lists + 64 * GS_THREADS - 1) / (64 * GS_THREADS);
+inline void gather_grid(int64_t groups, int64_t n_lists, int64_t* chunks_out, int64_t* q_per_block_out,
+                        int max_rounds = 128) {
+    int64_t chunks = (n_lists + (int64_t)max_rounds * GS_THREADS - 1) / ((int64_t)max_rounds * GS_THREADS);
     if (chunks < 1) chunks = 1;
     while (groups * chunks < 1024 && (n_lists + chunks - 1) / chunks > 4 * GS_THREADS) chunks *= 2;
     if (chunks > 65535) chunks = 65535;
@@ -1687,7 +1691,7 @@ int launch_gather_pivot(const float* X, int64_t n_rows, int nc, int64_t ldx, con
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
     const int64_t groups = (n_rows + R - 1) / R;
     int64_t chunks, q_per_block;
-    gather_grid(groups, n_lists, &chunks, &q_per_block);
+    gather_grid(groups, n_lists, &chunks, &q_per_block, MODE != 0 ? 64 : 128);
     // with APPLY the row groups are renumbered in sets of 8 x GP_XCD_GROUPS: pad the grid to whole sets
     const int64_t gx = MODE != 0 ? round_up(groups, 8 * GP_XCD_GROUPS) : groups;
     HYPMI_REQUIRE(gx <= 0x7fffffffLL, "gather_stats: too many rows");

@@ -23,6 +23,8 @@ cfg = dict(bench.WORKLOADS["asnorm_10k_128k"])
 cfg["n_test"] = int(sys.argv[2]) if len(sys.argv) > 2 else 196608
 if len(sys.argv) > 3:
     cfg["nbest"] = int(sys.argv[3])
+if os.environ.get("HYPMI_TEST_CHUNK"):
+    cfg["test_chunk"] = int(os.environ["HYPMI_TEST_CHUNK"])
 chain, model = bench.build_workload(cfg)
 plda = SPLDA(mu=model["mu"], V=model["V"], W=model["W"])
 preproc = TransformList([CentWhiten(mu=chain[0][1], T=chain[0][2], name="cw"), LNorm(name="ln"),
