@@ -117,6 +117,9 @@ SIGNATURES = {
     "hypmi_book_pack_f64": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, c_void_p, i64, c_void_p, c_void_p,
                                        c_void_p, c_void_p, ctypes.c_int, ctypes.c_double, c_void_p,
                                        ctypes.c_int, c_void_p]),
+    "hypmi_book_pack_f64_rows": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, c_void_p, i64, c_void_p, c_void_p,
+                                                c_void_p, c_void_p, ctypes.c_int, ctypes.c_double, c_void_p,
+                                                ctypes.c_int, c_void_p, i64, c_void_p, c_void_p]),
     "hypmi_scatter_block": (ctypes.c_int, [c_void_p, i64, c_void_p, i64, c_void_p, i64, c_void_p, i64,
                                            c_void_p]),
     "hypmi_topk_workspace_bytes": (i64, [i64, ctypes.c_int]),

@@ -60,7 +60,9 @@ __global__ __launch_bounds__(256) void book_pack_kernel(const T* __restrict__ s,
                                                         const T* __restrict__ scale_t,
                                                         const T* __restrict__ shift_n,
                                                         const T* __restrict__ scale_n, int side,
-                                                        double c, float* __restrict__ G, int KP) {
+                                                        double c, float* __restrict__ G, int KP,
+                                                        double* __restrict__ G64, int64_t ldg,
+                                                        float* __restrict__ bnd) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
@@ -69,18 +71,30 @@ __global__ __launch_bounds__(256) void book_pack_kernel(const T* __restrict__ s,
     double sg = 0.0, sh = 0.0;
     for (int k = lane; k < K; k += 64) {
         const double v = src[k];
-        const float gv = (float)((v + (double)shift_t[k]) * (double)scale_t[k]);
+        const double gd = (v + (double)shift_t[k]) * (double)scale_t[k];
         const double hv = (v + (double)shift_n[k]) * (double)scale_n[k];
-        sg += (double)gv * gv;
+        // q from the unrounded g: |g|^2 and |h|^2 are each about count times larger than their
+        // difference, so the rounding of g to fp32 (|g|^2 2^-24) must not enter it
+        sg += gd * gd;
         sh += hv * hv;
-        g[k] = gv;
+        g[k] = (float)gd;
+        if (G64) G64[i * ldg + k] = gd;
     }
-    const double q = 0.5 * (wave_sum_d(sg) - wave_sum_d(sh));
+    sg = wave_sum_d(sg);
+    sh = wave_sum_d(sh);
+    const double q = 0.5 * (sg - sh);
     for (int k = K + lane; k < KP; k += 64) {
         float v = 0.f;
         if (k == K) v = side == HYPMI_SIDE_ENROL ? (float)q : 1.f;
         if (k == K + 1) v = side == HYPMI_SIDE_ENROL ? 1.f : (float)(q + c);
         g[k] = v;
+    }
+    if (G64 && lane == 0) {  // the same row in float64: what a refinement pass scores with
+        const double q64 = q + (side == HYPMI_SIDE_TEST ? c : 0.0);
+        G64[i * ldg + K] = q64;
+        G64[i * ldg + K + 1] = sqrt(sg);
+        bnd[2 * i] = (float)sqrt(sg);
+        bnd[2 * i + 1] = (float)fabs(q64);
     }
 }
 
@@ -152,7 +166,7 @@ extern "C" int hypmi_book_pack(const float* s, int64_t lds_, int K, const int32_
     if (n == 0) return HYPMI_OK;
     hipLaunchKernelGGL(book_pack_kernel<float>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), s, lds_, K, rows, n, shift_t, scale_t, shift_n,
-                       scale_n, side, c, G, kp);
+                       scale_n, side, c, G, kp, (double*)nullptr, (int64_t)0, (float*)nullptr);
     HYPMI_HIP(hipGetLastError());
     return HYPMI_OK;
 }
@@ -160,13 +174,22 @@ extern "C" int hypmi_book_pack(const float* s, int64_t lds_, int K, const int32_
 extern "C" int hypmi_book_pack_f64(const double* s, int64_t lds_, int K, const int32_t* rows, int64_t n,
                                    const double* shift_t, const double* scale_t, const double* shift_n,
                                    const double* scale_n, int side, double c, float* G, int kp, void* stream) {
+    return hypmi_book_pack_f64_rows(s, lds_, K, rows, n, shift_t, scale_t, shift_n, scale_n, side, c, G, kp,
+                                    nullptr, 0, nullptr, stream);
+}
+
+extern "C" int hypmi_book_pack_f64_rows(const double* s, int64_t lds_, int K, const int32_t* rows, int64_t n,
+                                        const double* shift_t, const double* scale_t, const double* shift_n,
+                                        const double* scale_n, int side, double c, float* G, int kp,
+                                        double* G64, int64_t ldg, float* bnd, void* stream) {
     HYPMI_REQUIRE(s && shift_t && scale_t && shift_n && scale_n && G, "book_pack_f64: null pointer");
     HYPMI_REQUIRE(K > 0 && kp >= K + 2 && kp % 8 == 0 && lds_ >= K && n >= 0, "book_pack_f64: bad shape");
     HYPMI_REQUIRE(side == HYPMI_SIDE_ENROL || side == HYPMI_SIDE_TEST, "book_pack_f64: bad side");
+    HYPMI_REQUIRE(G64 == nullptr || (bnd != nullptr && ldg >= K + 2), "book_pack_f64: float64 rows need bounds and ldg >= K + 2");
     if (n == 0) return HYPMI_OK;
     hipLaunchKernelGGL(book_pack_kernel<double>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), s, lds_, K, rows, n, shift_t, scale_t, shift_n,
-                       scale_n, side, c, G, kp);
+                       scale_n, side, c, G, kp, G64, ldg, bnd);
     HYPMI_HIP(hipGetLastError());
     return HYPMI_OK;
 }

@@ -200,8 +200,11 @@ class ExactPass:
         torch = engine.require_gpu()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return self
+        from ..backend import settle_for_gloo
+
         world = dist.get_world_size(group)
         counts = torch.empty((world, 2), dtype=torch.int64, device="cuda")
+        settle_for_gloo(self.out, group)
         dist.all_gather_into_tensor(counts, self.count.view(1, 2), group=group)
         lists = torch.empty((world,) + tuple(self.out.shape), dtype=torch.float32, device="cuda")
         dist.all_gather_into_tensor(lists, self.out.unsqueeze(0).contiguous(), group=group)

@@ -540,13 +540,28 @@ class PLDABase(HypModel):
         return self._result(engine.score(G1, G2), x1, x2)
 
     def _stats_dev(self, x, ids):
+        """(N, F, None) of by-the-book scoring with F on the device: float64 class sums for host
+        vectors (the reference pools and centres in float64), fp32 ones for device tensors."""
+        torch = engine.require_gpu()
+        if not isinstance(x, torch.Tensor):
+            order, offsets, counts = _group_index(ids)
+            X = engine.upload64(x)
+            if order.shape[0] != X.shape[0]:
+                raise ValueError("%d class ids for %d rows" % (order.shape[0], X.shape[0]))
+            return counts.astype(np.float64), engine.pool64(X, order, offsets), None
         F_dev, counts = pool_rows(engine.upload(x), ids, mean=False)
         return counts.astype(np.float64), F_dev, None
 
-    def llr_NvsM_book(self, D1, D2):
+    def llr_NvsM_book(self, D1, D2, refine=None):
         """By-the-book multi-session scoring (splda.py:318-379, frplda.py:305-366,
         plda.py:474-539) from statistics D = (N, F, S); F as device tensors on both sides gives a
         device matrix back.
+
+        refine: as in llr_1vs1 -- every block's scores whose fp32 error bound is not below half of
+        1e-4 |s| are re-evaluated in float64 on the device from float64 packed rows (classes of many
+        segments carry |q| in the thousands next to scores of order ten: all of their scores).
+        Default: on when the statistics of both sides are float64 (host arrays, or device float64
+        sums), off for fp32 device statistics, whose own rounding is then the limit.
 
         Every count n needs L(n) = I + n VV (or B + n W); instead of one Cholesky per count the
         first-order statistics are projected once onto the eigen-basis that diagonalises all L(n)
@@ -568,17 +583,17 @@ class PLDABase(HypModel):
             N = np.asarray(D[0], dtype=np.float64)
             F = D[1]
             lds_ = engine.round_up(K, 4)
-            if not isinstance(F, torch.Tensor):
+            if not isinstance(F, torch.Tensor) or F.dtype == torch.float64:
                 # Host statistics arrive in float64 (the reference centres them in float64,
                 # splda.py:326-327): project them in float64 so that F - N mu does not cancel in fp32,
                 # and round only the projected statistics.
-                F64 = np.ascontiguousarray(F, dtype=np.float64)
+                F64 = engine.upload64(F)
                 n, d = F64.shape
                 s = torch.zeros((max(n, 1), K), dtype=torch.float64, device="cuda")
                 if n:
-                    aug64 = np.concatenate([F64, N[:, None]], axis=1)
+                    aug64 = torch.cat([F64, torch.from_numpy(N).to(F64.device)[:, None]], dim=1)
                     W64 = np.concatenate([bf["P"].T, np.asarray(bf["row_bias"], dtype=np.float64)[:, None]], axis=1)
-                    engine.gemm64(engine.upload64(aug64), engine.upload64(W64), out=s[:n])
+                    engine.gemm64(aug64, engine.upload64(W64), out=s[:n])
                 sides.append((N, s))
                 continue
             F_dev = engine.upload(F)
@@ -599,6 +614,11 @@ class PLDABase(HypModel):
             sides.append((N, s))
         (N1, s1), (N2, s2) = sides
         lam = bf["lam"]
+        both64 = s1.dtype == torch.float64 and s2.dtype == torch.float64
+        if refine is None:
+            refine = both64
+        elif refine and not both64:
+            raise ValueError("float64 refinement of by-the-book scores needs float64 statistics on both sides")
 
         def vec(a, like=None):  # a map in the precision of the statistics it is applied to
             dt = np.float64 if like is not None and like.dtype == torch.float64 else np.float32
@@ -619,15 +639,27 @@ class PLDABase(HypModel):
                     sh_t, sh_n = vec(bf["shift_t"], s), vec(bf["shift_n"], s)  # alive until the launch
                     G = torch.empty((len(rows), kp), dtype=torch.float32, device="cuda")
                     r_dev = torch.from_numpy(rows).cuda()
-                    pack = lib.hypmi_book_pack_f64 if s.dtype == torch.float64 else lib.hypmi_book_pack
-                    _lib.check(pack(engine._ptr(s), s.stride(0), K, engine._ptr(r_dev), len(rows),
-                                    engine._ptr(sh_t), engine._ptr(sc_t), engine._ptr(sh_n), engine._ptr(sc_n), side, c,
-                                    engine._ptr(G), kp, engine.stream_ptr()))
-                    Gs.append((G, r_dev))
+                    G64 = bnd = None
+                    if refine:
+                        G64 = torch.empty((len(rows), K + 2), dtype=torch.float64, device="cuda")
+                        bnd = torch.empty((len(rows), 2), dtype=torch.float32, device="cuda")
+                        _lib.check(lib.hypmi_book_pack_f64_rows(
+                            engine._ptr(s), s.stride(0), K, engine._ptr(r_dev), len(rows), engine._ptr(sh_t),
+                            engine._ptr(sc_t), engine._ptr(sh_n), engine._ptr(sc_n), side, c, engine._ptr(G), kp,
+                            engine._ptr(G64), K + 2, engine._ptr(bnd), engine.stream_ptr()))
+                    else:
+                        pack = lib.hypmi_book_pack_f64 if s.dtype == torch.float64 else lib.hypmi_book_pack
+                        _lib.check(pack(engine._ptr(s), s.stride(0), K, engine._ptr(r_dev), len(rows),
+                                        engine._ptr(sh_t), engine._ptr(sc_t), engine._ptr(sh_n), engine._ptr(sc_n),
+                                        side, c, engine._ptr(G), kp, engine.stream_ptr()))
+                    Gs.append((G, r_dev, G64, bnd))
                 if single:
-                    engine.score(Gs[0][0], Gs[1][0], out=out[:, :n2])
+                    blk = engine.score(Gs[0][0], Gs[1][0], out=out[:, :n2])
                 else:
                     blk = engine.score(Gs[0][0], Gs[1][0])
+                if refine and blk.numel():
+                    engine.refine_scores(blk, Gs[0][2], Gs[0][3], Gs[1][2], Gs[1][3], rel_tol=0.5e-4)
+                if not single:
                     _lib.check(lib.hypmi_scatter_block(engine._ptr(blk), blk.stride(0),
                                                        engine._ptr(Gs[0][1]), len(i),
                                                        engine._ptr(Gs[1][1]), len(j), engine._ptr(out),

@@ -232,10 +232,19 @@ int hypmi_book_pack(const float* s, int64_t lds, int K, const int32_t* rows, int
 
 /* The same from float64 statistics and float64 maps (same reference lines): for classes of many
  * segments |g|^2 - |h|^2 cancels to about 1 / count of either term, which needs the maps in double;
- * g is rounded to fp32 once, q is taken from the rounded g and the double h. */
+ * q is taken from the double g and h, g is rounded to fp32 once. */
 int hypmi_book_pack_f64(const double* s, int64_t lds, int K, const int32_t* rows, int64_t n,
                         const double* shift_t, const double* scale_t, const double* shift_n,
                         const double* scale_n, int side, double c, float* G, int kp, void* stream);
+
+/* hypmi_book_pack_f64 that also writes the rows hypmi_refine_scores works from (same reference lines,
+ * kept in float64 as splda.py:334-375 computes them): G64[n x ldg] = [g (unrounded), q (+ c on the test
+ * side) from the unrounded g, |g|], ldg >= K + 2, and bnd[n x 2] = (|g|, |q|) as floats.  With G64 ==
+ * NULL it is hypmi_book_pack_f64. */
+int hypmi_book_pack_f64_rows(const double* s, int64_t lds, int K, const int32_t* rows, int64_t n,
+                             const double* shift_t, const double* scale_t, const double* shift_n,
+                             const double* scale_n, int side, double c, float* G, int kp, double* G64,
+                             int64_t ldg, float* bnd, void* stream);
 
 /* out[ri[a], ci[b]] = blk[a, b]: the `scores[np.ix_(i, j)] = scores_ij` of splda.py:376. */
 int hypmi_scatter_block(const float* blk, int64_t ldb, const int32_t* ri, int64_t nr, const int32_t* ci,

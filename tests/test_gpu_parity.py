@@ -123,13 +123,16 @@ def test_nvsm_from_stats(golden, kind):
 
 
 def test_book_large_counts_and_offset_mean():
-    """By-the-book scoring from host statistics of classes with about a thousand segments and a model
-    mean far from the origin (|mu| = 40 x the spread): the centring F - N mu is done in float64
-    and the per-count maps are applied in float64 as in the reference (splda.py:326-375).  What is left
-    is the fp32 packed row itself: with a thousand segments a side |q| reaches several thousand while
-    the score is of order ten, and q is carried in fp32 (2^-24 relative), so the bound here is 1e-3 of
-    max(|score|, 1) rather than 1e-4 (no float64 refinement pass exists for by-the-book scoring).
+    """By-the-book scoring of classes with about a thousand segments and a model mean far from the
+    origin (|mu| = 40 x the spread): the centring F - N mu is done in float64 and the per-count maps
+    are applied in float64 as in the reference (splda.py:326-375).  With a thousand segments a side
+    |q| reaches several thousand while the score is of order ten, which an fp32 packed row cannot
+    carry to 1e-4 of the score; host statistics and host vectors therefore go through the float64
+    refinement pass (every score of such a block is re-evaluated from float64 packed rows) and meet
+    1e-4 of max(|score|, 1); fp32 device statistics keep the fp32 rows and 1e-3.
     Against the oracle (the reference's test data hold no such case: parity pinned by the oracle only)."""
+    import torch
+
     import synth
 
     m = synth.make_splda(48, 10)
@@ -144,8 +147,23 @@ def test_book_large_counts_and_offset_mean():
     N1, F1, _ = O.compute_stats_hard(x1, ids1)
     N2, F2, _ = O.compute_stats_hard(x2, ids2)
     ref = O.llr_NvsM_book(m, (N1.copy(), F1.copy(), None), (N2.copy(), F2.copy(), None))
-    s = make("splda", m).llr_NvsM((N1, F1, None), (N2, F2, None), method="book")
-    assert_scores(s, ref, rtol=1e-3)
+    model = make("splda", m)
+    F1c, F2c = F1.copy(), F2.copy()
+    s = model.llr_NvsM((N1, F1, None), (N2, F2, None), method="book")
+    assert_scores(s, ref, rtol=1e-4)
+    assert np.array_equal(F1, F1c) and np.array_equal(F2, F2c)
+    # from the vectors themselves (float64 class sums on the device), both entry points
+    assert_scores(model.llr_NvsM(x1, x2, ids1=ids1, ids2=ids2, method="book"), ref, rtol=1e-4)
+    ref1 = O.llr_NvsM_book(m, (N1.copy(), F1.copy(), None), (np.ones(len(x2)), x2.copy(), None))
+    assert_scores(model.llr_Nvs1(x1, x2, ids1=ids1, method="book"), ref1, rtol=1e-4)
+    # without the pass: the fp32 rows alone (what device fp32 statistics get)
+    s32 = model.llr_NvsM_book((N1, F1, None), (N2, F2, None), refine=False)
+    assert_scores(s32, ref, rtol=1e-3)
+    sd = model.llr_NvsM_book((N1, torch.from_numpy(F1).float().cuda(), None),
+                             (N2, torch.from_numpy(F2).float().cuda(), None))
+    assert isinstance(sd, torch.Tensor) and sd.dtype == torch.float32
+    with pytest.raises(ValueError):
+        model.llr_NvsM_book((N1, torch.from_numpy(F1).float().cuda(), None), (N2, F2, None), refine=True)
 
 
 def test_compute_stats_hard(golden):
