@@ -65,6 +65,86 @@ def all_gather_lists(local, counts, group=None):
 LAZY_MAX_COHORT = 40_960  # largest cohort the register-resident top-k kernel takes
 
 
+class SnormMemoryPlan(dict):
+    """HBM budget of one rank of the chain -> PLDA -> adaptive S-norm pipeline, in bytes, and the tile
+    shape chosen from it: `test_chunk` tests per chunk and `enrol_block` enrolment rows per tile.
+    Keys: resident (packed rows, enrol-vs-cohort panel, lists), per_chunk (test-vs-cohort panel, lists
+    and packed rows of one chunk of tests), per_tile (the [enrol_block, test_chunk] intermediates),
+    result (the materialised matrix, 0 when it is streamed), total, budget."""
+
+
+def plan_snorm_memory(n_enrol, n_cohort, n_test, nbest, row_bytes, budget_bytes, test_chunk=65536,
+                      materialise=True, tile_arrays=4, exact=True, x_dim=0, min_chunk=4096, min_block=1024,
+                      tile_bytes=None, resident_allocated=False):
+    """Sizes the adaptive S-norm pipeline of one rank before anything is allocated.
+
+    The job grid of the reference gives every process one block of the trial matrix and lets the
+    operating system find out whether it fits (egs/voxceleb/v1/steps_be/eval_be_v1.sh:33-60); here the
+    rank computes what it will hold -- nothing of it grows with the number of tests except the
+    materialised result -- picks the largest chunk of tests (<= test_chunk) and block of enrolment rows
+    that fit `budget_bytes`, and raises MemoryError with the numbers when even the smallest tile does not.
+
+    row_bytes: bytes of one packed row in the score kernel's operand format.  tile_arrays: fp32
+    [enrol_block, test_chunk] arrays alive per tile (4 on the fused path: raw scores, the two T-part
+    statistics, the normalised block; 8 unfused).  tile_bytes: optional cap on the per-tile part alone.
+    resident_allocated: the enrolment / cohort side is in memory already and `budget_bytes` is what is
+    left beside it.  Pure arithmetic (no device needed)."""
+    ne, nc, nt, k = int(n_enrol), int(n_cohort), int(n_test), int(nbest)
+    ld_c = (nc + 31) // 32 * 32
+    k8 = (k + 7) // 8 * 8
+    f64_row = 8 * 152 if exact else 0  # upper bound of a float64 packed row (K + 2 doubles, K <= 150 typical)
+    resident = (ne * (row_bytes + 8)                 # enrolment packed rows + (|g|, |q|) bounds
+                + nc * (row_bytes + f64_row + 8)     # cohort rows, fp32 operand and float64
+                + ne * ld_c * 4                      # enrol-vs-cohort panel
+                + 2 * ne * k8 * 2)                   # enrolment top-k lists: local + gathered
+    result = ne * ((nt + 31) // 32 * 32) * 4 if materialise else 0
+
+    def per_chunk(c):
+        return c * (ld_c * 4 + 2 * row_bytes + 8 + k8 * 2 + 4 * x_dim)  # panel, both packings, bounds, lists, chain scratch
+
+    def per_tile(b, c):
+        return tile_arrays * 4 * (b + 32) * (c + 32)
+
+    held = 0 if resident_allocated else resident
+    avail = int(budget_bytes) - held - result
+    chunk = max(1, min(int(test_chunk), nt))
+    while True:
+        room = avail - per_chunk(chunk)
+        if tile_bytes is not None:
+            room = min(room, int(tile_bytes))
+        block = ne
+        if per_tile(ne, chunk) > room:
+            block = room // (tile_arrays * 4 * (chunk + 32)) - 32
+            block = block // min_block * min_block
+        if block >= min(min_block, ne):
+            break
+        if chunk <= min_chunk:
+            need = held + result + per_chunk(chunk) + per_tile(min(min_block, ne), chunk)
+            raise MemoryError(
+                "adaptive S-norm of %d enrolment models x %d tests against a %d-member cohort does not fit: "
+                "%.1f GB resident%s (enrol-vs-cohort panel %.1f GB) + %.1f GB result + %.1f GB for the smallest "
+                "tile (%d tests x %d models) = %.1f GB to allocate, %.1f GB available -- shard the enrolment set "
+                "or stream the result (reduce=)"
+                % (ne, nt, nc, resident / 1e9, " (already held)" if resident_allocated else "", ne * ld_c * 4 / 1e9,
+                   result / 1e9, (need - held - result) / 1e9, chunk, min(min_block, ne), need / 1e9,
+                   budget_bytes / 1e9))
+        chunk = max(min_chunk, chunk // 2)
+    plan = SnormMemoryPlan(resident=resident, result=result, per_chunk=per_chunk(chunk),
+                           per_tile=per_tile(block, chunk), test_chunk=chunk, enrol_block=block,
+                           budget=int(budget_bytes))
+    plan["total"] = resident + result + plan["per_chunk"] + plan["per_tile"]  # what the rank holds at its peak
+    return plan
+
+
+def device_budget(fraction=0.9):
+    """Bytes this process may still use on the current device: what the driver reports free plus what
+    torch's allocator holds without using, times `fraction`."""
+    torch = engine.require_gpu()
+    free, _ = torch.cuda.mem_get_info()
+    cached = torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
+    return int(fraction * (free + cached))
+
+
 def _take64(x, lo, hi, rows):
     """Rows `rows` (device int32, relative to lo) of x[lo:hi] as device float64, from the caller's own
     array (a float64 host array keeps the digits its fp32 device copy lost)."""
@@ -89,11 +169,13 @@ class PLDABackend:
         self.nbest = int(nbest)
         self.nbest_discard = int(nbest_discard)
         self.test_chunk = int(test_chunk)
-        # bound on the six [enrol, chunk] fp32 intermediates of one tile (two pairs of cohort statistics,
-        # raw and normalised scores): with more enrolment models than this allows per chunk of tests the
-        # enrolment rows are walked in blocks, so that the chunk of tests can stay long (every workgroup of
-        # the statistics kernels amortises its rows over the lists of one tile)
+        # cap (bytes, or None) on the [enrol, chunk] fp32 intermediates of one tile; less when the device
+        # has less free when score_snorm starts (see plan_snorm_memory).  With more enrolment models than
+        # fit per chunk of tests the enrolment rows are walked in blocks, so that the chunk of tests can
+        # stay long (every workgroup of the statistics kernels amortises its rows over the lists of one tile)
         self.tile_bytes = 96 << 30
+        self.memory_fraction = 0.85  # share of the free device memory the pipeline may plan with
+        self.last_memory_plan = None
         # finish the normalisation inside the Z-part statistics kernel (no separate apply pass)
         self.fuse_apply = True
         self.pair_stats = True  # fused path: T-part mean and 1 / std side by side (one line per list in the Z part)
@@ -140,6 +222,26 @@ class PLDABackend:
         self.trace.append((name, e0, e1, shape))
         return r
 
+    def memory_plan(self, n_enrol, n_cohort, n_test, materialise=True, resident_allocated=False, fused=True,
+                    budget_bytes=None):
+        """plan_snorm_memory for this backend's plan and settings against the memory the device has
+        free now (or `budget_bytes`); with resident_allocated the enrolment / cohort side is taken to be
+        in memory already (score_snorm after prepare_cohort).  Raises MemoryError before anything is
+        allocated when the job cannot fit; the plan is kept in `last_memory_plan`."""
+        from . import _lib
+
+        fmt = engine.DEFAULT_SPLIT
+        row_bytes = int(getattr(_lib.load(), engine.SPLIT_FORMATS[fmt][0])(self.plan.kp)) or 4 * self.plan.kp
+        if budget_bytes is None:
+            budget_bytes = device_budget(self.memory_fraction)
+        k = min(self.nbest, max(1, n_cohort - self.nbest_discard))
+        mp = plan_snorm_memory(n_enrol, n_cohort, n_test, k, row_bytes, budget_bytes, self.test_chunk,
+                               materialise=materialise, tile_arrays=4 if fused else 8, exact=self.exact_topk,
+                               x_dim=self.plan.d_in, tile_bytes=self.tile_bytes,
+                               resident_allocated=resident_allocated)
+        self.last_memory_plan = mp
+        return mp
+
     # ---- embeddings ---------------------------------------------------------------------------
     def embed(self, x, side):
         """Raw vectors (numpy or device tensor) -> packed device rows for one side of a trial."""
@@ -157,6 +259,8 @@ class PLDABackend:
         global (the only inter-GPU exchange of the whole pipeline)."""
         xc = engine.upload(x_cohort)
         nc_all = xc.shape[0]
+        # what stays resident for the whole job, checked before the panel is allocated
+        self.memory_plan(len(x_enrol), nc_all, 0, materialise=False)
         # fp64 rows only for the rows whose top-k boundary is in doubt (see topk_rows): needs the bounds
         # the pair-writing prologue kernel gives and the register-resident selection kernel
         lazy = self.exact_topk and self.lazy_exact and self.plan.pairs_in_prologue() and nc_all <= LAZY_MAX_COHORT
@@ -211,16 +315,17 @@ class PLDABackend:
         nt = xt.shape[0]
         Ge, A_ec, e_idx, k = cohort["Ge"], cohort["A_ec"], cohort["e_idx"], cohort["k"]
         ne = Ge.shape[0]
+        fused = self.fuse_apply and gather_apply_supported(A_ec.shape[1], ne)
+        # tile shape from the memory this rank still has (the cohort panel and lists are already resident),
+        # before the result or anything else is allocated
+        mp = self.memory_plan(ne, A_ec.shape[1], nt, materialise=out is None and reduce is None,
+                              resident_allocated=True, fused=fused and self.pair_stats)
+        test_chunk, eb = mp["test_chunk"], mp["enrol_block"]
         if out is None and reduce is None:
             ld = engine.round_up(max(nt, 1), 32)
             out = torch.empty((ne, ld), dtype=torch.float32, device=xt.device)[:, :nt]
-        fused = self.fuse_apply and gather_apply_supported(A_ec.shape[1], ne)
-        chunk = max(1, min(self.test_chunk, nt))
-        eb = ne  # enrolment rows per tile
-        if 24 * ne * chunk > self.tile_bytes:
-            eb = max(1024, self.tile_bytes // (24 * chunk) // 1024 * 1024)
-        for c0 in range(0, nt, self.test_chunk):
-            c1 = min(nt, c0 + self.test_chunk)
+        for c0 in range(0, nt, test_chunk):
+            c1 = min(nt, c0 + test_chunk)
             xc = xt[c0:c1]
             T = self._timed
             # tests as rows of the cohort panel and as columns of the trial matrix

@@ -87,6 +87,10 @@ extern "C" void hypmi_plan_destroy(hypmi_plan* p) {
     delete p;
 }
 
+namespace {
+int static_scratch(void** out);
+}
+
 extern "C" int hypmi_plan_create(const hypmi_plan_desc* d, hypmi_plan** out) {
     HYPMI_REQUIRE(d && out, "plan_create: null argument");
     HYPMI_REQUIRE(d->d_in > 0, "plan_create: d_in must be positive");
@@ -262,6 +266,12 @@ extern "C" int hypmi_plan_create(const hypmi_plan_desc* d, hypmi_plan** out) {
             }
             f.enabled = rc == HYPMI_OK;
         }
+    }
+    if (rc == HYPMI_OK && p->K > 0) {
+        // hypmi_prologue_noalloc must not resolve a symbol inside a stream capture: the address of this
+        // device's scratch array is looked up here, where the plan's device is current
+        void* unused = nullptr;
+        rc = static_scratch(&unused);
     }
     if (rc != HYPMI_OK) {
         hypmi_plan_destroy(p);
@@ -478,11 +488,11 @@ __global__ __launch_bounds__(256) void prologue_fused_kernel(
             double sg = 0.0, sh = 0.0;
             for (int k = lane; k < K; k += 64) {
                 const double v = z[k];
-                const float gv = (float)((v + (double)shift_t[k]) * (double)scale_t[k]);
+                const double gd = (v + (double)shift_t[k]) * (double)scale_t[k];
                 const double hv = (v + (double)shift_n[k]) * (double)scale_n[k];
-                sg += (double)gv * gv;
+                sg += gd * gd;  // q from the unrounded g, as book_pack_kernel takes it
                 sh += hv * hv;
-                z[k] = gv;
+                z[k] = (float)gd;
             }
             const double tg = wave_sum(sg);
             const double q = 0.5 * (tg - wave_sum(sh));
@@ -723,7 +733,7 @@ extern "C" int hypmi_prologue_noalloc(const hypmi_plan* p, const float* x, int64
                   "use hypmi_prologue with a workspace",
                   (long long)n, (long long)max_rows, (long long)STATIC_SCRATCH_BYTES);
     void* ws = nullptr;
-    int rc = static_scratch(&ws);
+    int rc = static_scratch(&ws);  // resolved when the plan was created on this device: a table look-up
     if (rc != HYPMI_OK) return rc;
     // Every intermediate row is written by its producing kernel before anything reads it and nothing
     // is accumulated in place, so what the previous call left behind needs no clearing.

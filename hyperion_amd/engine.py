@@ -63,11 +63,7 @@ def upload(x, dtype=None):
             and x.dtype.isnative and x.dtype.kind == "f" and x.dtype.itemsize in (2, 8)):
         # a wide host type: narrowed by torch's threaded copy into a page-locked buffer and sent from
         # there (numpy's serial astype plus a pageable copy take four times as long)
-        stage = _pinned("up32", x.size, torch.float32)[:x.size].view(n, d)
-        stage.copy_(_as_tensor(x))
-        t = stage.to(device="cuda", non_blocking=True)
-        torch.cuda.current_stream().synchronize()  # the buffer is reused by the next call
-        return t
+        return _upload_staged(x, torch.float32)
     host = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
     if ld == d:
         return host.cuda()
@@ -87,32 +83,69 @@ def upload64(x):
     x = np.ascontiguousarray(x, dtype=np.float64)
     if x.size < (1 << 20):
         return torch.from_numpy(x).cuda()
-    stage = _pinned("up64", x.size, torch.float64)[:x.size].view(x.shape)
-    stage.copy_(_as_tensor(x))
-    t = stage.to(device="cuda", non_blocking=True)
-    torch.cuda.current_stream().synchronize()  # the buffer is reused by the next call
-    return t
+    return _upload_staged(x, torch.float64)
+
+
+# Page-locked staging: at most this many bytes per buffer (two buffers per direction and thread), whatever
+# the size of the array that passes through; larger arrays go in row slices.
+STAGE_BYTES = 256 << 20
+
+
+def _upload_staged(x, dtype):
+    """C-contiguous host array [n, d] -> device tensor of `dtype`, through two page-locked buffers of at
+    most STAGE_BYTES each in row slices: the conversion of slice i + 1 (torch's threaded copy) runs
+    while slice i is on the link; an event per buffer says when it may be filled again."""
+    torch = _torch()
+    n, d = x.shape
+    out = torch.empty((n, d), dtype=dtype, device="cuda")
+    item = out.element_size()
+    rows = max(1, min(n, STAGE_BYTES // max(1, d * item)))
+    src = _as_tensor(x)
+    stream = torch.cuda.current_stream()
+    bufs = [_pinned("up%d_%d" % (item, i), rows * d, dtype) for i in range(2 if rows < n else 1)]
+    busy = [None] * len(bufs)
+    for i, r0 in enumerate(range(0, n, rows)):
+        r1 = min(n, r0 + rows)
+        b = i % len(bufs)
+        if busy[b] is not None:
+            busy[b].synchronize()
+        stage = bufs[b][:(r1 - r0) * d].view(r1 - r0, d)
+        stage.copy_(src[r0:r1])
+        out[r0:r1].copy_(stage, non_blocking=True)
+        busy[b] = torch.cuda.Event()
+        busy[b].record(stream)
+    for e in busy:
+        if e is not None:
+            e.synchronize()  # the buffers are reused by the next call
+    return out
 
 
 def _as_tensor(x):
-    """torch view of a host array that is only read (a read-only array would draw torch's warning
-    about writes through the view)."""
-    import warnings
-
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore", UserWarning)
-        return _torch().from_numpy(x)
+    """torch view of a C-contiguous host array that is only read.  torch warns about writes through a
+    view of a read-only array; such an array is therefore aliased through its address (no copy, no
+    process-wide warning filter, nothing shared between threads).  The caller keeps `x` alive."""
+    if not x.flags.writeable and x.nbytes:
+        assert x.flags.c_contiguous
+        raw = (ctypes.c_byte * x.nbytes).from_address(x.ctypes.data)
+        x = np.frombuffer(raw, dtype=x.dtype).reshape(x.shape)
+    return _torch().from_numpy(x)
 
 
 def _pinned(key, numel, dtype):
-    """Cached page-locked host buffer of at least `numel` elements."""
+    """Cached page-locked host buffer of at least `numel` elements (one set per calling thread, never
+    more than STAGE_BYTES each; drop_staging() releases them)."""
     torch = _torch()
     staging = _staging.__dict__
     buf = staging.get(key)
     if buf is None or buf.numel() < numel or buf.dtype != dtype:
-        buf = torch.empty(max(numel, 1 << 22), dtype=dtype, pin_memory=True)
+        buf = torch.empty(max(numel, 1 << 20), dtype=dtype, pin_memory=True)
         staging[key] = buf
     return buf
+
+
+def drop_staging():
+    """Releases the calling thread's page-locked staging buffers (they are made again on demand)."""
+    _staging.__dict__.clear()
 
 
 _blas_pools = None
@@ -551,16 +584,31 @@ _staging = threading.local()  # page-locked buffers, one set per calling thread
 
 
 def to_host(t, dtype):
-    """Device tensor -> numpy array of the host float type.  Large results go through a cached
-    page-locked staging buffer (pageable device-to-host copies run at a fraction of the link rate)
-    and are widened to the host type by torch's threaded copy rather than numpy's serial astype."""
+    """Device tensor -> numpy array of the host float type.  Large results go through page-locked
+    staging buffers of at most STAGE_BYTES (pageable device-to-host copies run at a fraction of the link
+    rate), in row slices, and are widened to the host type by torch's threaded copy rather than numpy's
+    serial astype; the widening of slice i overlaps the transfer of slice i + 1."""
     torch = _torch()
     n = t.numel()
-    if n < (1 << 16) or t.dtype != torch.float32:
+    if n < (1 << 16) or t.dtype != torch.float32 or t.dim() != 2:
         return t.cpu().numpy().astype(dtype, copy=False)
-    stage = _pinned("down32", n, torch.float32)[:n].view(t.shape)
-    stage.copy_(t, non_blocking=True)
-    torch.cuda.current_stream().synchronize()
-    out = np.empty(tuple(t.shape), dtype=dtype)
-    torch.from_numpy(out).copy_(stage)
+    r, c = t.shape
+    out = np.empty((r, c), dtype=dtype)
+    dst = torch.from_numpy(out)
+    rows = max(1, min(r, STAGE_BYTES // max(1, 4 * c)))
+    bufs = [_pinned("down32_%d" % i, rows * c, torch.float32) for i in range(2 if rows < r else 1)]
+    stream = torch.cuda.current_stream()
+    pending = None  # (buffer view, destination rows, event) of the slice in flight
+    for i, r0 in enumerate(range(0, r, rows)):
+        r1 = min(r, r0 + rows)
+        stage = bufs[i % len(bufs)][:(r1 - r0) * c].view(r1 - r0, c)
+        stage.copy_(t[r0:r1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        if pending is not None:
+            pending[2].synchronize()
+            dst[pending[1][0]:pending[1][1]].copy_(pending[0])
+        pending = (stage, (r0, r1), ev)
+    pending[2].synchronize()
+    dst[pending[1][0]:pending[1][1]].copy_(pending[0])
     return out

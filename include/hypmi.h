@@ -133,7 +133,10 @@ int hypmi_prologue_pairs_bounds(const hypmi_plan* plan, const float* x, int64_t 
  * in a 16 MiB array inside the library's device image, one per GPU, held until the process ends.
  * No counterpart in the reference.  Same arguments, result and stream ordering as hypmi_prologue;
  * n may not exceed hypmi_prologue_noalloc_max_rows(plan) (3167 rows for a 512 -> 512 -> 200 chain
- * with K = 150), larger n is refused with an error.  It calls no hipMalloc / hipFree.  All calls on
+ * with K = 150), larger n is refused with an error.  It calls no hipMalloc / hipFree.  The array's
+ * device address is resolved by hypmi_plan_create on the device that is current there (once per
+ * device); a call on another device than the plan's resolves it on first use, which must then
+ * happen outside a stream capture.  All calls on
  * one GPU share that GPU's array: calls that may overlap there (different streams or threads)
  * race; keep them on one stream or order them yourself. */
 int64_t hypmi_prologue_noalloc_max_rows(const hypmi_plan* plan);

@@ -898,11 +898,15 @@ def test_adapt_s_norm_warns_when_boundary_is_not_redecided():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("d,lda,K,n", [(512, 200, 150, 1000), (512, 200, 150, 64), (96, 40, 12, 333), (99, 37, 10, 1)])
+@pytest.mark.parametrize("d,lda,K,n", [(512, 200, 150, 1000), (512, 200, 150, 64), (96, 40, 12, 333), (99, 37, 10, 1),
+                                       (512, 200, 150, 262144 + 77), (96, 40, 12, 262144 + 5)])
 def test_prologue_pairs_equals_prologue_then_pair_rows(d, lda, K, n):
     """The prologue kernel that writes fp16 pairs itself against the same plan's packed rows converted
     by the stand-alone kernel: the pairs, the inverse scales and the optional packed rows, bit for
-    bit, on both sides of a trial, rows that do not fill the last workgroup included."""
+    bit, on both sides of a trial, rows that do not fill the last workgroup included.  From 262 144
+    rows in one launch the pair-writing entry point runs its 128-row tile, while hypmi_prologue (chunks
+    of at most 65 536 rows) always runs the 64-row one: the two largest cases compare the two tile
+    shapes, with a ragged last workgroup."""
     import torch
 
     import synth
@@ -917,7 +921,10 @@ def test_prologue_pairs_equals_prologue_then_pair_rows(d, lda, K, n):
                         LDA(mu=chain[2][1], T=chain[2][2], name="lda")])
     plan = SPLDA(mu=m["mu"], V=m["V"], W=m["W"]).score_plan(tl)
     assert _lib.load().hypmi_prologue_pairs_supported(plan._h) == 1
-    x = engine.upload(np.random.RandomState(n).randn(n, d).astype(np.float32) * 2)
+    if n < 100_000:
+        x = engine.upload(np.random.RandomState(n).randn(n, d).astype(np.float32) * 2)
+    else:
+        x = engine.upload(torch.randn((n, d), device="cuda", generator=torch.Generator(device="cuda").manual_seed(n)) * 2)
     for side in (SIDE_ENROL, SIDE_TEST):
         G = plan.prologue(x, side)
         want = engine.split_rows(G, "pair")
