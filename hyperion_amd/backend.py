@@ -65,6 +65,11 @@ def all_gather_lists(local, counts, group=None):
 LAZY_MAX_COHORT = 40_960  # largest cohort the register-resident top-k kernel takes
 
 
+# enrolment rows one workgroup of the T-part statistics kernel walks at most (128 rounds of 1024 lists): blocks
+# of a multiple of it leave no short last workgroup per test
+WALK_ROWS = 128 * 1024
+
+
 class SnormMemoryPlan(dict):
     """HBM budget of one rank of the chain -> PLDA -> adaptive S-norm pipeline, in bytes, and the tile
     shape chosen from it: `test_chunk` tests per chunk and `enrol_block` enrolment rows per tile.
@@ -116,6 +121,8 @@ def plan_snorm_memory(n_enrol, n_cohort, n_test, nbest, row_bytes, budget_bytes,
         if per_tile(ne, chunk) > room:
             block = room // (tile_arrays * 4 * (chunk + 32)) - 32
             block = block // min_block * min_block
+            if block >= WALK_ROWS:
+                block = block // WALK_ROWS * WALK_ROWS
         if block >= min(min_block, ne):
             break
         if chunk <= min_chunk:
@@ -174,6 +181,9 @@ class PLDABackend:
         # fit per chunk of tests the enrolment rows are walked in blocks, so that the chunk of tests can
         # stay long (every workgroup of the statistics kernels amortises its rows over the lists of one tile)
         self.tile_bytes = 96 << 30
+        # operands of the score kernel: "pair" (scaled fp16 pairs, the default), "triple" (exact bf16 triples)
+        # or None: fp32 packed rows on the fp32 matrix cores
+        self.split_format = engine.DEFAULT_SPLIT
         self.memory_fraction = 0.85  # share of the free device memory the pipeline may plan with
         self.last_memory_plan = None
         # finish the normalisation inside the Z-part statistics kernel (no separate apply pass)
@@ -230,8 +240,9 @@ class PLDABackend:
         allocated when the job cannot fit; the plan is kept in `last_memory_plan`."""
         from . import _lib
 
-        fmt = engine.DEFAULT_SPLIT
-        row_bytes = int(getattr(_lib.load(), engine.SPLIT_FORMATS[fmt][0])(self.plan.kp)) or 4 * self.plan.kp
+        fmt = self.split_format
+        row_bytes = int(getattr(_lib.load(), engine.SPLIT_FORMATS[fmt][0])(self.plan.kp)) if fmt else 0
+        row_bytes = row_bytes or 4 * self.plan.kp
         if budget_bytes is None:
             budget_bytes = device_budget(self.memory_fraction)
         k = min(self.nbest, max(1, n_cohort - self.nbest_discard))
@@ -243,13 +254,38 @@ class PLDABackend:
         return mp
 
     # ---- embeddings ---------------------------------------------------------------------------
+    def _bounds_of(self, G, side):
+        """(|g|, |q|) of fp32 packed rows [g, q, 1] / [g, 1, q + c]: what the pair-writing prologue kernel
+        returns beside its rows, for the fp32 operand format."""
+        torch = engine.require_gpu()
+        K = self.plan.k
+        return torch.stack([G[:, :K].norm(dim=1), G[:, K if side == SIDE_ENROL else K + 1].abs()], dim=1).contiguous()
+
+    def _embed(self, x, side, bounds=False):
+        fmt = self.split_format
+        if fmt is None:
+            G = self.plan.prologue(x, side)
+            return (G, self._bounds_of(G, side)) if bounds else G
+        return self.plan.prologue_split(x, side, fmt, bounds=bounds)
+
+    def _embed_both(self, x, bounds=False):
+        fmt = self.split_format
+        if fmt is None:
+            Ge, Gt = self.plan.prologue(x, SIDE_ENROL), self.plan.prologue(x, SIDE_TEST)
+            return (Ge, Gt, self._bounds_of(Ge, SIDE_ENROL)) if bounds else (Ge, Gt)
+        return self.plan.prologue_split_both(x, fmt, bounds=bounds)
+
+    def _lazy_ok(self):
+        """Whether per-row bounds come with the fp32 prologue (then float64 rows are made only where needed)."""
+        return self.split_format is None or self.plan.pairs_in_prologue(self.split_format)
+
     def embed(self, x, side):
         """Raw vectors (numpy or device tensor) -> packed device rows for one side of a trial."""
-        return self.plan.prologue_split(engine.upload(x), side)
+        return self._embed(engine.upload(x), side)
 
     def score(self, x_enrol, x_test, out=None):
         """Raw PLDA log-likelihood ratios, device [n_enrol, n_test]."""
-        return engine.score(self.embed(x_enrol, SIDE_ENROL), self.embed(x_test, SIDE_TEST), out=out)
+        return engine.score(self.embed(x_enrol, SIDE_ENROL), self.embed(x_test, SIDE_TEST), out=out, split=False)
 
     # ---- scoring with adaptive S-norm -----------------------------------------------------------
     def prepare_cohort(self, x_enrol, x_cohort, rank=0, world=1, group=None):
@@ -263,15 +299,15 @@ class PLDABackend:
         self.memory_plan(len(x_enrol), nc_all, 0, materialise=False)
         # fp64 rows only for the rows whose top-k boundary is in doubt (see topk_rows): needs the bounds
         # the pair-writing prologue kernel gives and the register-resident selection kernel
-        lazy = self.exact_topk and self.lazy_exact and self.plan.pairs_in_prologue() and nc_all <= LAZY_MAX_COHORT
+        lazy = self.exact_topk and self.lazy_exact and self._lazy_ok() and nc_all <= LAZY_MAX_COHORT
         xe = engine.upload(x_enrol)
         be_rows = None
         if lazy:
-            Ge, be_rows = self._timed("prologue", lambda: self.plan.prologue_split(xe, SIDE_ENROL, bounds=True))
+            Ge, be_rows = self._timed("prologue", lambda: self._embed(xe, SIDE_ENROL, bounds=True))
         else:
-            Ge = self._timed("prologue", lambda: self.plan.prologue_split(xe, SIDE_ENROL))
-        Gc_test = self._timed("prologue", lambda: self.plan.prologue_split(xc, SIDE_TEST))
-        A_ec = self._timed("score_enrol_cohort", lambda: engine.score(Ge, Gc_test))
+            Ge = self._timed("prologue", lambda: self._embed(xe, SIDE_ENROL))
+        Gc_test = self._timed("prologue", lambda: self._embed(xc, SIDE_TEST))
+        A_ec = self._timed("score_enrol_cohort", lambda: engine.score(Ge, Gc_test, split=False))
         ne, nc = A_ec.shape
         assert self.nbest_discard < nc
         k = min(self.nbest, nc - self.nbest_discard)
@@ -331,12 +367,12 @@ class PLDABackend:
             # tests as rows of the cohort panel and as columns of the trial matrix
             exact = None
             if cohort.get("coh64") is not None and cohort.get("lazy"):
-                Gt_rows, Gt_cols, bt = T("prologue", lambda: self.plan.prologue_split_both(xc, bounds=True))
+                Gt_rows, Gt_cols, bt = T("prologue", lambda: self._embed_both(xc, bounds=True))
                 exact = dict(cohort["coh64"], bnd_rows=bt, defer=True,
                              rows64=lambda rows: self.plan.prologue_f64(_take64(x_test, c0, c1, rows), SIDE_ENROL))
             else:
-                Gt_rows, Gt_cols = T("prologue", lambda: self.plan.prologue_split_both(xc))
-            A_tc = T("score_test_cohort", lambda: engine.score(Gt_rows, cohort["Gc_test"]))  # [chunk, cohort]
+                Gt_rows, Gt_cols = T("prologue", lambda: self._embed_both(xc))
+            A_tc = T("score_test_cohort", lambda: engine.score(Gt_rows, cohort["Gc_test"], split=False))  # [chunk, cohort]
             if cohort.get("coh64") is not None and exact is None:
                 def f64_rows():
                     Gt64, bt = self.plan.prologue_f64(engine.upload64(x_test[c0:c1]), SIDE_ENROL)
@@ -348,7 +384,7 @@ class PLDABackend:
                 e1 = min(ne, e0 + eb)
                 # the trial scores before the two gathers: the score kernel pulls the clock down, and a gather
                 # that starts behind it runs its first half millisecond at that clock
-                S = T("score_trials", lambda: engine.score(_rows(Ge, e0, e1), Gt_cols))   # [enrol, chunk]
+                S = T("score_trials", lambda: engine.score(_rows(Ge, e0, e1), Gt_cols, split=False))   # [enrol, chunk]
                 paired = fused and self.pair_stats
                 if paired:
                     mt, ldt = T("gather_t", lambda: gather_stats_pairs(A_tc, e_idx[:, e0:e1], e1 - e0, 1e-5, k),
