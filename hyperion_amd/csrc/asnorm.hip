@@ -1267,6 +1267,13 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
     // Entries past the end of a list (the last group holds krem of them) are redirected to a slot
     // of zeros behind the rows: a zero adds nothing to either moment.
     if (tid < R) xr[(size_t)nc * R + tid] = 0.f;  // `red` is no longer needed
+    // The lists of the block are handed out to the waves in units of 64 (unit u = lists q0 + 64 u ...): a
+    // wave starts with units `wave` and `wave + 16` and then takes the next one nobody has, from a counter in
+    // LDS.  The waves of a SIMD do not advance at the same rate (arbitration by age, LDS conflicts of their own
+    // lists); with a fixed share each the first wave of a workgroup finished well before the last, and a SIMD
+    // with one or two waves left cannot fill its issue slots.
+    unsigned* unit_counter = reinterpret_cast<unsigned*>(xr + (size_t)nc * R + 8);
+    if (tid == 0) *unit_counter = 2 * (GS_THREADS / 64);
     __syncthreads();
     unsigned keep[4], fill[4];
 #pragma unroll
@@ -1275,43 +1282,61 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
         keep[w] = (lo_ok ? 0xffffu : 0u) | (hi_ok ? 0xffff0000u : 0u);
         fill[w] = (lo_ok ? 0u : (unsigned)nc) | (hi_ok ? 0u : (unsigned)nc << 16);
     }
-    // lists per lane (the last may be missing) and index groups per lane: the same in every lane of a
-    // wave.  A wave none of whose lanes has a list in the block's last round leaves that round out.
-    const int nl_all = __builtin_amdgcn_readfirstlane((int)((q1 - q0 + GS_THREADS - 1) / GS_THREADS));
-    const int64_t wave_first_last = (int64_t)(nl_all - 1) * GS_THREADS + 64 * __builtin_amdgcn_readfirstlane(wave);
-    const int nl = nl_all - (wave_first_last >= q1 - q0 ? 1 : 0);
-    if (nl == 0) return;  // (no barrier follows)
-    const int n = nl * G;  // the launcher keeps this below 2^31
+    constexpr int WAVES = GS_THREADS / 64;
+    const int U = __builtin_amdgcn_readfirstlane((int)((q1 - q0 + 63) >> 6));  // units of the block
+    const int uw = __builtin_amdgcn_readfirstlane(wave);
+    if (uw >= U) return;  // (no barrier follows)
+    // A unit is claimed one unit ahead of the index stream, which itself runs GP_RING groups ahead of the
+    // arithmetic; with lists of at most GP_RING groups the stream could cross two units before the
+    // arithmetic has left one, and the shares stay fixed (unit u is followed by u + 16).
+    const bool dynamic = G > GP_RING;
     const uint4* base = reinterpret_cast<const uint4*>(idx8);
-    // A lane without a list in the last round walks the block's last list and stores nothing.
-    // The index loads of a lane form one stream over (list, group).  Its address is a uniform part --
-    // group g of the lists of round l starts at idx8 + (g ldi + q0 + 1024 l) 16 bytes, stepped with
-    // scalar instructions -- plus 16 bytes per lane, so the loads go through a buffer descriptor
-    // (scalar base, per-lane offset) and the stream costs no vector instruction besides the load.
+    // The index loads of a wave form one stream over (unit, group).  Group g of unit u starts at
+    // idx8 + (g ldi + q0 + 64 u) 16 bytes -- a uniform address, stepped with scalar instructions -- plus 16
+    // bytes per lane, so the loads go through a buffer descriptor (scalar base, per-lane offset) and the
+    // stream costs no vector instruction besides the load.  The descriptor ends behind the last list of the
+    // block: lanes of the last unit that have no list read zeros (and store nothing).
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
-    const char* sp = reinterpret_cast<const char*>(idx8) + q0 * 16;  // uniform
-    const int64_t step_b = ldi * 16, hop_b = ((int64_t)GS_THREADS - (int64_t)(G - 1) * ldi) * 16;
-    const int64_t last_lists = (q1 - q0) - (int64_t)(nl_all - 1) * GS_THREADS;  // lists of the last round, 1..1024
-    const unsigned voff_last = (unsigned)(tid < last_lists ? tid : last_lists - 1) * 16u;
-    unsigned voff = nl_all == 1 ? voff_last : (unsigned)tid * 16u;
-    int l_ld = 0, g_ld = 0;  // uniform
-    uint4 ring[GP_RING];
+    const char* sp0 = reinterpret_cast<const char*>(idx8) + q0 * 16;  // uniform
+    const int64_t step_b = ldi * 16;
+    const unsigned voff = (unsigned)lane * 16u;
+    int u_ld = uw, u_next = uw + WAVES, g_ld = 0;  // uniform: unit and group of the next load, the unit after it
+    unsigned claim = 0;                            // lane 0: the unit claimed at the last crossing
+    const char* sp = sp0 + (int64_t)u_ld * 1024;
+    unsigned nrec = (unsigned)((q1 - q0 - 64 * (int64_t)u_ld < 64 ? q1 - q0 - 64 * (int64_t)u_ld : 64) * 16);
+    int u_after = u_next;  // the unit the arithmetic takes after its current one
 #define HYPMI_NEXT_LOAD(dst)                                                                              \
     {                                                                                                     \
         const v4u w_ = __builtin_amdgcn_raw_buffer_load_b128(                                             \
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sp), 0, 16 * GS_THREADS, 0x00020000), voff, 0, 0); \
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(sp), 0, nrec, 0x00020000), voff, 0, 0);   \
         dst = make_uint4(w_[0], w_[1], w_[2], w_[3]);                                                     \
         if (++g_ld < G) {                                                                                 \
             sp += step_b;                                                                                 \
-        } else if (l_ld + 1 < nl) {                                                                       \
+        } else if (u_ld < U) {                                                                            \
+            /* the stream moves on to the next unit of this wave and claims the one after that */         \
             g_ld = 0;                                                                                     \
-            ++l_ld;                                                                                       \
-            sp += hop_b;                                                                                  \
-            if (l_ld == nl_all - 1) voff = voff_last;                                                     \
+            u_ld = u_next;                                                                                \
+            u_after = u_ld;                                                                               \
+            if (dynamic) {                                                                                \
+                u_next = __builtin_amdgcn_readfirstlane(claim);                                           \
+                if (lane == 0) claim = atomicAdd(unit_counter, 1u);                                       \
+            } else {                                                                                      \
+                u_next = u_ld + WAVES;                                                                    \
+            }                                                                                             \
+            if (u_ld < U) {                                                                               \
+                const int64_t left = q1 - q0 - 64 * (int64_t)u_ld;                                        \
+                sp = sp0 + (int64_t)u_ld * 1024;                                                          \
+                nrec = (unsigned)((left < 64 ? left : 64) * 16);                                          \
+            } else {                                                                                      \
+                sp -= (int64_t)(G - 1) * step_b; /* the stream is over: further loads re-read a unit */   \
+            }                                                                                             \
         } else {                                                                                          \
-            g_ld = G - 1; /* the stream is over: further loads re-read its last group */                  \
+            g_ld = 0;                                                                                     \
+            sp -= (int64_t)(G - 1) * step_b;                                                              \
         }                                                                                                 \
     }
+    // the first claim: it is picked up when the stream crosses into the wave's second unit
+    if (dynamic && lane == 0) claim = atomicAdd(unit_counter, 1u);
     // APPLY: what the end of a list needs from global memory -- the raw scores of the R rows and the R
     // transposed statistics (one 4 R-byte load each) -- is requested when the list begins, so that the
     // requests of the sixteen waves (which reach the ends of their lists together) have a whole list's
@@ -1319,9 +1344,9 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
     typename LdsVec<R>::type pm, pi;
     typename LdsVec<2 * R>::type pmi;  // PAIRS: (mean, 1 / std) of row 0, of row 1, ...
     float ps[R];
-#define HYPMI_APPLY_PREFETCH(LIST)                                                                  \
+#define HYPMI_APPLY_PREFETCH(UNIT)                                                                  \
     if (APPLY) {                                                                                    \
-        int64_t qq = q0 + tid + (int64_t)(LIST) * GS_THREADS;                                       \
+        int64_t qq = q0 + lane + (int64_t)(UNIT) * 64;                                              \
         qq = qq < q1 ? qq : q1 - 1;                                                                 \
         if (PAIRS) {                                                                                \
             pmi = load_pairs<R>(ap.mt + (qq * ap.ldt + r0) * 2);                                    \
@@ -1334,7 +1359,9 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
             ps[rr] = __builtin_nontemporal_load(ap.S + e * ap.lds + qq);                            \
         }                                                                                           \
     }
-    HYPMI_APPLY_PREFETCH(0)
+    int u_cp = uw;  // the unit of the arithmetic
+    HYPMI_APPLY_PREFETCH(u_cp)
+    uint4 ring[GP_RING];
 #pragma unroll
     for (int d = 0; d < GP_RING; ++d) HYPMI_NEXT_LOAD(ring[d])
 
@@ -1345,10 +1372,11 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
     const float inv_k = 1.0f / (float)k, floor2 = floor_ * floor_, inv_floor = 1.0f / floor_;
     // One group of eight entries from ring slot D: addresses, then all eight reads, then the arithmetic
     // (the fences keep the reads of a group in flight together instead of one wait per read).  The
-    // slot is reloaded (RELOAD) once its contents have become addresses, so that the new group can take
-    // the registers of the old one; in the main loop every slot is reloaded unconditionally, which
-    // lets the compiler count the loads in flight instead of waiting for all of them.
-#define HYPMI_GROUP(D, RELOAD)                                                                                  \
+    // slot is reloaded once its contents have become addresses, so that the new group can take the
+    // registers of the old one; every slot is reloaded unconditionally (behind the end of the stream the
+    // loads repeat its last unit), which lets the compiler count the loads in flight instead of waiting
+    // for all of them.
+#define HYPMI_GROUP(D)                                                                                          \
     {                                                                                                           \
         unsigned a[8];                                                                                          \
         if (krem != 0 && g == G - 1) {                                                                          \
@@ -1365,7 +1393,7 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
             a[6] = entry_addr<R, 0>(ring[D].w, xbase); a[7] = entry_addr<R, 1>(ring[D].w, xbase);               \
         }                                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
-        if (RELOAD) HYPMI_NEXT_LOAD(ring[D])                                                                    \
+        HYPMI_NEXT_LOAD(ring[D])                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                      \
         typename LdsVec<R>::type val[8];                                                                        \
         _Pragma("unroll") for (int e = 0; e < 8; ++e) val[e] = lds_vec<R>(a[e]);                                \
@@ -1375,7 +1403,7 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
                 moment_step(s1[rr], s2[rr], lds_vec_elem<R>(val[e], rr));                                       \
         if (++g == G) {                                                                                         \
             /* The sums carry fp32 rounding (about 1e-6 relative); so does this arithmetic. */                  \
-            const int64_t q = q0 + tid + (int64_t)l * GS_THREADS;                                               \
+            const int64_t q = q0 + lane + (int64_t)u_cp * 64;                                                   \
             const bool live_q = q < q1;                                                                         \
             float lp[R]; /* what the moments are taken around: the row pivot, or after a redo the list's own */ \
             bool redo = false;                                                                                  \
@@ -1419,22 +1447,20 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
             }                                                                                                   \
             g = 0;                                                                                              \
             ++l;                                                                                                \
+            u_cp = dynamic ? u_after : u_cp + WAVES;                                                            \
+            if (u_cp >= U) break; /* nothing left for this wave */                                              \
             rotate_priority((wave >> 2) + l);                                                                   \
-            if (l < nl) HYPMI_APPLY_PREFETCH(l)                                                                 \
+            HYPMI_APPLY_PREFETCH(u_cp)                                                                          \
         }                                                                                                       \
     }
     static_assert(GP_RING == 4, "the walk below names the four ring slots");
     rotate_priority(wave >> 2);
-    int i = 0;
-    for (; i + GP_RING <= n; i += GP_RING) {
-        HYPMI_GROUP(0, true)
-        HYPMI_GROUP(1, true)
-        HYPMI_GROUP(2, true)
-        HYPMI_GROUP(3, true)
+    for (;;) {
+        HYPMI_GROUP(0)
+        HYPMI_GROUP(1)
+        HYPMI_GROUP(2)
+        HYPMI_GROUP(3)
     }
-    if (i < n) HYPMI_GROUP(0, false)
-    if (i + 1 < n) HYPMI_GROUP(1, false)
-    if (i + 2 < n) HYPMI_GROUP(2, false)
 }
 
 #undef HYPMI_GROUP
