@@ -70,6 +70,8 @@ def parse(argv=None):
                     help="operands of the score kernel: scaled fp16 pairs, exact bf16 triples, or fp32")
     ap.add_argument("--test-chunk", type=int, default=None,
                     help="tests per chunk of the AS-norm pipeline (default: the workload's own, else 65536)")
+    ap.add_argument("--n-coh", type=int, default=None, help="cohort size of an AS-norm workload (sweeps)")
+    ap.add_argument("--n-test", type=int, default=None, help="tests per GPU (sweeps)")
     ap.add_argument("--dry-run", action="store_true",
                     help="start the ranks, form the process group, exchange one number, print the rank "
                          "count and stop (no GPU work): a check of the launch path")
@@ -712,6 +714,10 @@ def main():
     cfg = dict(WORKLOADS[args.workload])
     if args.test_chunk:
         cfg["test_chunk"] = args.test_chunk
+    if args.n_coh and "n_coh" in cfg:
+        cfg["n_coh"] = args.n_coh
+    if args.n_test:
+        cfg["n_test"] = args.n_test
     chain, model = build_workload(cfg)
     plda = SPLDA(mu=model["mu"], V=model["V"], W=model["W"])
     preproc = None

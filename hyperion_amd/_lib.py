@@ -130,6 +130,15 @@ SIGNATURES = {
                                           i64, ctypes.c_int, i64, ctypes.c_float, c_void_p, c_void_p,
                                           i64, c_void_p]),
     "hypmi_gather_apply_supported": (ctypes.c_int, [ctypes.c_int, i64]),
+    "hypmi_gather_seg_plan": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                             ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "hypmi_segment_lists": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, i64, ctypes.c_int, c_void_p, c_void_p,
+                                           c_void_p]),
+    "hypmi_gather_stats_seg": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, i64, c_void_p, c_void_p, c_void_p, i64,
+                                              ctypes.c_int, i64, ctypes.c_float, c_void_p, c_void_p, i64, c_void_p]),
+    "hypmi_gather_apply_seg": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, i64, c_void_p, c_void_p, c_void_p, i64,
+                                              ctypes.c_int, i64, ctypes.c_float, c_void_p, i64, c_void_p, i64,
+                                              c_void_p, i64, c_void_p]),
     "hypmi_gather_apply": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, i64, c_void_p, i64, ctypes.c_int, i64,
                                           ctypes.c_float, c_void_p, i64, c_void_p, c_void_p, i64, c_void_p, i64,
                                           c_void_p]),

@@ -15,8 +15,8 @@ import numpy as np
 
 from . import engine
 from .engine import SIDE_ENROL, SIDE_TEST
-from .score_norm.adapt_s_norm import (gather_apply, gather_apply_pairs, gather_apply_supported, gather_stats,
-                                      gather_stats_pairs, topk_rows)
+from .score_norm.adapt_s_norm import (gather_apply, gather_apply_pairs, gather_apply_supported, gather_pairs_supported,
+                                      gather_stats, gather_stats_pairs, seg_plan, topk_rows)
 
 
 def shard_range(n, part, num_parts):
@@ -62,7 +62,7 @@ def all_gather_lists(local, counts, group=None):
     return torch.cat([recv[r, :, :counts[r]] for r in range(world)], dim=1).contiguous()
 
 
-LAZY_MAX_COHORT = 40_960  # largest cohort the register-resident top-k kernel takes
+LAZY_MAX_COHORT = 65_536  # largest cohort the register-resident top-k kernel takes
 
 
 # enrolment rows one workgroup of the T-part statistics kernel walks at most (128 rounds of 1024 lists): blocks
@@ -351,11 +351,13 @@ class PLDABackend:
         nt = xt.shape[0]
         Ge, A_ec, e_idx, k = cohort["Ge"], cohort["A_ec"], cohort["e_idx"], cohort["k"]
         ne = Ge.shape[0]
-        fused = self.fuse_apply and gather_apply_supported(A_ec.shape[1], ne)
+        segmented = seg_plan(A_ec.shape[1], k) is not None  # the cohort is taken in segments: pairs only
+        fused = self.fuse_apply and (gather_pairs_supported(A_ec.shape[1], ne, k) if segmented
+                                     else gather_apply_supported(A_ec.shape[1], ne))
         # tile shape from the memory this rank still has (the cohort panel and lists are already resident),
         # before the result or anything else is allocated
         mp = self.memory_plan(ne, A_ec.shape[1], nt, materialise=out is None and reduce is None,
-                              resident_allocated=True, fused=fused and self.pair_stats)
+                              resident_allocated=True, fused=fused and (self.pair_stats or segmented))
         test_chunk, eb = mp["test_chunk"], mp["enrol_block"]
         if out is None and reduce is None:
             ld = engine.round_up(max(nt, 1), 32)
@@ -385,7 +387,7 @@ class PLDABackend:
                 # the trial scores before the two gathers: the score kernel pulls the clock down, and a gather
                 # that starts behind it runs its first half millisecond at that clock
                 S = T("score_trials", lambda: engine.score(_rows(Ge, e0, e1), Gt_cols, split=False))   # [enrol, chunk]
-                paired = fused and self.pair_stats
+                paired = fused and (self.pair_stats or segmented)
                 if paired:
                     mt, ldt = T("gather_t", lambda: gather_stats_pairs(A_tc, e_idx[:, e0:e1], e1 - e0, 1e-5, k),
                                 (nq, e1 - e0, k))                                         # [chunk, enrol, 2]

@@ -8,12 +8,13 @@
 //     T part:  X = A_tc, lists from A_ec rows  -> stats[t, e]
 // and the final kernel combines both with the raw score.
 //
-//   topk_rows     one workgroup per row; the row lives in LDS as order-preserving integer keys and
-//                 an 8-bit-per-pass radix select finds the boundary keys; ties at a boundary are
-//                 resolved by cohort index (lowest first), so the result is deterministic.
+//   topk_rows     one workgroup per row; the row lives in registers as order-preserving integer keys
+//                 and the boundary keys are found bit by bit; ties at a boundary are resolved by
+//                 cohort index (lowest first), so the result is deterministic.
 //   gather_stats  one workgroup per group of R rows of X held in LDS (interleaved, so one LDS read
 //                 returns the R values of a cohort member); lanes walk different lists and reuse
-//                 every index for the R rows.
+//                 every index for the R rows.  Cohorts that do not fit LDS two rows at a time are
+//                 taken in segments (gather_seg_kernel).
 //
 // Index lists are uint16 (cohort < 65536) in groups of eight: entry j of list q lives at
 // idx8[((j >> 3) * ldi + q) * 8 + (j & 7)], so a lane fetches eight consecutive entries of its list
@@ -22,68 +23,10 @@
 
 namespace {
 
-constexpr int TK_THREADS = 256;
 
 __device__ __forceinline__ unsigned key_of(float f) {
     const unsigned u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending float order == ascending key
-}
-
-// Radix select of the element at descending rank `want` (0-based) among keys[0..n):
-// returns its key and the number of keys strictly greater.  All threads of the block call it.
-__device__ void select_rank(const unsigned* __restrict__ keys, int n, int want, unsigned* hist,
-                            unsigned* bcast, unsigned* out_key, int* out_gt) {
-    const int tid = threadIdx.x;
-    unsigned prefix = 0, mask = 0;
-    int gt = 0;  // keys known to be greater than every key matching `prefix`
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        for (int b = tid; b < 256; b += TK_THREADS) hist[b] = 0;
-        __syncthreads();
-        for (int i = tid; i < n; i += TK_THREADS) {
-            const unsigned kx = keys[i];
-            if ((kx & mask) == prefix) atomicAdd(&hist[(kx >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        if (tid < 64) {
-            // wave 0: suffix sums over the 256 bins, 4 bins per lane (lane 63 owns bins 252..255)
-            const int lane = tid;
-            unsigned c[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) c[u] = hist[4 * lane + u];
-            const unsigned own = c[0] + c[1] + c[2] + c[3];
-            unsigned above = own;  // inclusive suffix sum over lanes >= lane
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned v = __shfl_down(above, off, 64);
-                if (lane + off < 64) above += v;
-            }
-            above -= own;  // keys in bins owned by higher lanes
-            const unsigned need = (unsigned)(want - gt);  // rank inside the current candidate set
-            // find the bin where the descending cumulative count first exceeds `need`
-            unsigned run = above;
-            int found = -1;
-            unsigned gt_in = 0;
-#pragma unroll
-            for (int u = 3; u >= 0; --u) {
-                if (found < 0 && run <= need && run + c[u] > need) {
-                    found = 4 * lane + u;
-                    gt_in = run;
-                }
-                run += c[u];
-            }
-            if (found >= 0) {  // exactly one lane finds it
-                bcast[0] = (unsigned)found;
-                bcast[1] = gt_in;
-            }
-        }
-        __syncthreads();
-        prefix |= bcast[0] << shift;
-        mask |= 255u << shift;
-        gt += (int)bcast[1];
-        __syncthreads();
-    }
-    *out_key = prefix;
-    *out_gt = gt;
 }
 
 __device__ __forceinline__ float float_of_key(unsigned key) {
@@ -112,186 +55,8 @@ struct ExactSrc {
 
 constexpr int TK_CAND = 64;  // boundary candidates re-decided per boundary
 
-// Boundary re-decision.  The fp32 selection puts the boundary of "rank < R" at value thr; entries
-// within +-delta of thr (delta = what fp32 cannot resolve) are candidates.  Entries above thr+delta are
-// certainly above; m = R - (their count) candidates must be above, chosen by exact value (ties by
-// index).  Fills cand_idx / cand_above and returns the number of candidates (0 = nothing to override).
-__device__ int redecide_boundary(const unsigned* __restrict__ keys, int nc, int R, float thr, float delta,
-                                 const ExactSrc& ex, int64_t row, unsigned* hist, unsigned* bcast,
-                                 unsigned short* cand_idx, unsigned char* cand_above) {
-    const int tid = threadIdx.x;
-    double* exact = reinterpret_cast<double*>(hist);  // 64 doubles alias the 256-bin histogram
-    if (tid == 0) {
-        bcast[0] = 0;  // entries certainly above
-        bcast[1] = 0;  // candidates
-    }
-    __syncthreads();
-    const float hi = thr + delta, lo = thr - delta;
-    unsigned n_above = 0;
-    for (int i = tid; i < nc; i += TK_THREADS) {
-        const float v = float_of_key(keys[i]);
-        if (v > hi) {
-            ++n_above;
-        } else if (v >= lo) {
-            const unsigned pos = atomicAdd(&bcast[1], 1u);
-            if (pos < TK_CAND) cand_idx[pos] = (unsigned short)i;
-        }
-    }
-    if (n_above) atomicAdd(&bcast[0], n_above);
-    __syncthreads();
-    const int n_cand = (int)bcast[1];
-    const int m = R - (int)bcast[0];
-    __syncthreads();
-    if (n_cand > TK_CAND) {
-        if (tid == 0 && ex.counters) atomicAdd(&ex.counters[1], 1ull);
-        return 0;
-    }
-    if (m <= 0 || m >= n_cand) return 0;  // all candidates on one side: nothing to decide
-    // exact values of the candidates
-    if (ex.mode == 1) {
-        if (tid < n_cand) exact[tid] = ex.A64[row * ex.lda64 + cand_idx[tid]];
-    } else {
-        const int grp = tid >> 4, sub = tid & 15;
-        const double* gr = ex.G_rows + row * ex.ldg;
-        for (int a = grp; a < n_cand; a += TK_THREADS / 16) {
-            const double* gc = ex.G_coh + (int64_t)cand_idx[a] * ex.ldg;
-            double acc = 0.0;
-            for (int kk = sub; kk < ex.K; kk += 16) acc = fma(gr[kk], gc[kk], acc);
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
-            if (sub == 0) exact[a] = acc + gr[ex.K] + gc[ex.K];
-        }
-    }
-    __syncthreads();
-    if (tid < n_cand) {
-        const double v = exact[tid];
-        const unsigned short me = cand_idx[tid];
-        int rank = 0;
-        for (int b2 = 0; b2 < n_cand; ++b2) {
-            const double w = exact[b2];
-            rank += (w > v || (w == v && cand_idx[b2] < me)) ? 1 : 0;
-        }
-        cand_above[tid] = rank < m ? 1 : 0;
-    }
-    __syncthreads();
-    if (tid == 0 && ex.counters) atomicAdd(&ex.counters[0], 1ull);
-    return n_cand;
-}
-
-// Writes the cohort indices ranked discard .. discard+k-1 of row `row`, in ascending index order,
-// into the grouped uint16 list layout; the unused tail of the last group of eight is zeroed.
-// An entry is selected iff it is above the boundary "rank < discard + k" and not above the boundary
-// "rank < discard"; rank = (#greater) + (#equal with a lower index).  With an exact source, entries
-// that fp32 cannot separate from a boundary value are re-decided from their float64 values.
-template <bool USE_LDS>
-__global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float* __restrict__ A, int64_t lda,
-                                                               int nc, int k, int discard,
-                                                               uint16_t* __restrict__ idx8, int64_t ldi,
-                                                               unsigned* __restrict__ gkeys, ExactSrc ex) {
-    extern __shared__ __attribute__((aligned(16))) unsigned smem[];
-    unsigned* hist = smem;          // 256 (aliased by 64 doubles during boundary re-decision)
-    unsigned* bcast = smem + 256;   // 4
-    unsigned* wtot = smem + 260;    // 4 waves x 2 counters (+ pad)
-    unsigned short* cand_idx = reinterpret_cast<unsigned short*>(smem + 272);  // 2 x TK_CAND
-    unsigned char* cand_above = reinterpret_cast<unsigned char*>(smem + 272 + TK_CAND);  // 2 x TK_CAND
-    unsigned* keys = USE_LDS ? smem + 368 : gkeys + (int64_t)blockIdx.x * nc;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t row = blockIdx.x;
-    const float* src = A + row * lda;
-    for (int i = tid; i < nc; i += TK_THREADS) keys[i] = key_of(src[i]);
-    if (tid < 8 && k + tid < ((k + 7) & ~7)) {
-        const int j = k + tid;
-        idx8[((int64_t)(j >> 3) * ldi + row) * 8 + (j & 7)] = 0;
-    }
-    __syncthreads();
-
-    const int last = discard + k;
-    unsigned key_hi, key_lo = 0xffffffffu;
-    int gt_hi, gt_lo = 0;
-    select_rank(keys, nc, last - 1, hist, bcast, &key_hi, &gt_hi);
-    if (discard > 0) select_rank(keys, nc, discard - 1, hist, bcast, &key_lo, &gt_lo);
-
-    // what fp32 cannot resolve around a boundary value
-    int n_hi = 0, n_lo = 0;
-    float thr_hi = 0.f, thr_lo = 0.f, d_hi = 0.f, d_lo = 0.f;
-    if (ex.mode != 0) {
-        thr_hi = float_of_key(key_hi);
-        thr_lo = float_of_key(key_lo);
-        if (ex.mode == 1) {  // the fp32 matrix is the rounding of the fp64 one
-            d_hi = fabsf(thr_hi) * 2.4e-7f;
-            d_lo = fabsf(thr_lo) * 2.4e-7f;
-        } else {
-            const float bound = ex.err_coeff * (ex.bnd_rows[2 * row] * ex.coh_gmax + ex.bnd_rows[2 * row + 1] +
-                                                ex.coh_qmax);
-            d_hi = d_lo = 2.f * bound;
-        }
-        n_hi = redecide_boundary(keys, nc, last, thr_hi, d_hi, ex, row, hist, bcast, cand_idx, cand_above);
-        if (discard > 0)
-            n_lo = redecide_boundary(keys, nc, discard, thr_lo, d_lo, ex, row, hist, bcast, cand_idx + TK_CAND,
-                                     cand_above + TK_CAND);
-    }
-
-    // ordered compaction
-    int eq_hi_seen = 0, eq_lo_seen = 0, written = 0;
-    for (int base = 0; base < nc; base += TK_THREADS) {
-        const int i = base + tid;
-        const bool valid = i < nc;
-        const unsigned kx = valid ? keys[i] : 0u;
-        const bool is_hi = valid && kx == key_hi;
-        const bool is_lo = valid && discard > 0 && kx == key_lo;
-        const unsigned long long m_hi = __ballot(is_hi), m_lo = __ballot(is_lo);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        if (lane == 0) {
-            wtot[2 * wave] = (unsigned)__popcll(m_hi);
-            wtot[2 * wave + 1] = (unsigned)__popcll(m_lo);
-        }
-        __syncthreads();
-        int hi_before = eq_hi_seen + __popcll(m_hi & below), lo_before = eq_lo_seen + __popcll(m_lo & below);
-        int hi_tot = 0, lo_tot = 0;
-#pragma unroll
-        for (int w = 0; w < TK_THREADS / 64; ++w) {
-            if (w < wave) {
-                hi_before += (int)wtot[2 * w];
-                lo_before += (int)wtot[2 * w + 1];
-            }
-            hi_tot += (int)wtot[2 * w];
-            lo_tot += (int)wtot[2 * w + 1];
-        }
-        bool sel = false;
-        if (valid) {
-            bool above_hi = kx > key_hi || (is_hi && gt_hi + hi_before < last);
-            bool above_lo = discard > 0 && (kx > key_lo || (is_lo && gt_lo + lo_before < discard));
-            if (n_hi | n_lo) {
-                const float v = float_of_key(kx);
-                if (n_hi && fabsf(v - thr_hi) <= d_hi)
-                    for (int a2 = 0; a2 < n_hi; ++a2)
-                        if (cand_idx[a2] == i) above_hi = cand_above[a2] != 0;
-                if (n_lo && fabsf(v - thr_lo) <= d_lo)
-                    for (int a2 = 0; a2 < n_lo; ++a2)
-                        if (cand_idx[TK_CAND + a2] == i) above_lo = cand_above[TK_CAND + a2] != 0;
-            }
-            sel = above_hi && !above_lo;
-        }
-        __syncthreads();  // wtot is rewritten below
-        const unsigned long long m_sel = __ballot(sel);
-        if (lane == 0) wtot[2 * wave] = (unsigned)__popcll(m_sel);
-        __syncthreads();
-        int pos = written + __popcll(m_sel & below), tot = 0;
-#pragma unroll
-        for (int w = 0; w < TK_THREADS / 64; ++w) {
-            if (w < wave) pos += (int)wtot[2 * w];
-            tot += (int)wtot[2 * w];
-        }
-        if (sel && pos < k) idx8[((int64_t)(pos >> 3) * ldi + row) * 8 + (pos & 7)] = (uint16_t)i;
-        written += tot;
-        eq_hi_seen += hi_tot;
-        eq_lo_seen += lo_tot;
-        __syncthreads();
-    }
-}
-
-// ---- register-resident top-k (cohorts up to 40 960) ---------------------------------------------
-// One workgroup of 256 threads per row; thread t keeps the keys of cohort members t, t + 256, ... in
+// ---- register-resident top-k ----------------------------------------------------------------------
+// One workgroup of 256 (long rows: 512) threads per row; thread t keeps the keys of cohort members t, t + 256, ... in
 // ITEMS registers (no LDS copy of the row, no atomics on it).  The key at descending rank `want` is
 // found bit by bit from the top: the answer has bit b set iff more than `want` keys are
 // >= (prefix | 1 << b).  One step is ITEMS compares per thread, a ballot count per wave and one
@@ -301,30 +66,36 @@ __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float* __re
 // the compares of the ~28 remaining steps, 256 costs two more full passes and more often leaves the
 // uncertainty band of the boundary outside the bracket.)  Several such workgroups share a CU, so the
 // barriers of one overlap the compares of the others.
-constexpr int TR_THREADS = 256, TR_WAVES = TR_THREADS / 64;
+constexpr int TR_THREADS = 256;    // threads per row of up to 24 576 members, twice as many above
+constexpr int TR_MAX_WAVES = 8;
 constexpr int TR_CAND = 512;     // the bracket is narrow once it holds at most this many keys
 constexpr int TR_STAGE = 8192;    // longest list staged in LDS before it is written (entries)
 constexpr int TR_ORDER = 2048;    // longest list that leaves ordered by LDS bank class
-constexpr int TR_MAX_ITEMS = 160;
-constexpr int TR_MAX_NC = TR_MAX_ITEMS * TR_THREADS;
+constexpr int TR_MAX_NC = 128 * 512;  // longest row: 512 threads with 128 keys each
 
 struct TopkShared {
-    unsigned cnt[2][TR_WAVES];             // per-wave counters, alternating between steps
+    unsigned cnt[2][TR_MAX_WAVES];         // per-wave counters, alternating between steps
     unsigned ncand;                        // candidates written so far / boundary candidates
     unsigned cand[TR_CAND]; // keys inside the bracket
 };
 
 // Sum over the workgroup of a per-wave count (one barrier; the counter slots alternate so that the
 // next call may start before every wave has read this one).
+template <int WAVES>
 __device__ __forceinline__ int block_sum(TopkShared& sh, int& par, unsigned wave_count, int lane, int wave) {
     // The count is pinned in a scalar register here: sunk into the lane-0 branch below, its popcounts
     // would keep every ballot mask of the caller alive across that branch.
     asm volatile("" : "+s"(wave_count));
     if (lane == 0) sh.cnt[par][wave] = wave_count;
     __syncthreads();
-    const uint4 v = *reinterpret_cast<const uint4*>(sh.cnt[par]);
+    unsigned sum = 0;
+#pragma unroll
+    for (int q = 0; q < WAVES / 4; ++q) {
+        const uint4 v = *reinterpret_cast<const uint4*>(sh.cnt[par] + 4 * q);
+        sum += (v.x + v.y) + (v.z + v.w);
+    }
     par ^= 1;
-    return (int)(v.x + v.y + v.z + v.w);
+    return (int)sum;
 }
 
 // Makes the compiler forget what it knows about x (no instruction): keeps it from carrying dozens of
@@ -366,7 +137,7 @@ struct BandProbe {
     int in_band;   // out: keys with t - delta <= value <= t + delta (valid when known)
 };
 
-template <int ITEMS>
+template <int ITEMS, int THREADS>
 struct TopkRegs {
     unsigned key[ITEMS];
 
@@ -392,7 +163,7 @@ struct TopkRegs {
         for (; b >= 0; --b) {
             if (c_lo - c_hi <= TR_CAND && b < 31) break;
             const unsigned cand = prefix | (1u << b);
-            const int c = block_sum(sh, par, wave_count([cand](unsigned kx) { return kx >= cand; }), lane, wave);
+            const int c = block_sum<THREADS / 64>(sh, par, wave_count([cand](unsigned kx) { return kx >= cand; }), lane, wave);
             if (c > want) {
                 prefix = cand;
                 c_lo = c;
@@ -474,24 +245,25 @@ struct TopkRegs {
     }
 };
 
-template <int ITEMS>
+template <int ITEMS, int THREADS>
 __device__ __forceinline__ void topk_rows_reg_body(const float* __restrict__ A, int64_t lda, int nc, int k,
                                                    int discard, uint16_t* __restrict__ idx8, int64_t ldi,
                                                    const ExactSrc& ex) {
     __shared__ __attribute__((aligned(16))) TopkShared sh;
+    constexpr int TR_WAVES = THREADS / 64;
     __shared__ unsigned tab[TR_WAVES * ((ITEMS + 63) / 64) * 64];  // per (wave, item) counts for the ordered compaction
     __shared__ double exact_s[TK_CAND];
     __shared__ unsigned short cand_idx[2 * TK_CAND];
     __shared__ unsigned char cand_above[2 * TK_CAND];
     __shared__ __attribute__((aligned(16))) unsigned short stage[TR_STAGE];
     __shared__ __attribute__((aligned(16))) unsigned short ordered[TR_ORDER];
-    __shared__ unsigned short bank_cnt[8][32];
+    __shared__ unsigned short bank_cnt[THREADS / 32][32];
     __shared__ unsigned short bank_start[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t xrow = blockIdx.x;  // row of the exact values and bounds
     const int64_t row = ex.row_map ? ex.row_map[xrow] : xrow;
     int par = 0;
-    TopkRegs<ITEMS> R;
+    TopkRegs<ITEMS, THREADS> R;
     const float* src = A + row * lda;
     // All loads of the row are issued before the first use (clamped index, no branch per item).
     // Key 0 is reserved for "no element": real keys are at least 1 (only the all-ones NaN maps lower).
@@ -499,13 +271,13 @@ __device__ __forceinline__ void topk_rows_reg_body(const float* __restrict__ A, 
         float raw[ITEMS];
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
-            const int i = j * TR_THREADS + tid;
+            const int i = j * THREADS + tid;
             raw[j] = __builtin_nontemporal_load(src + (i < nc ? i : nc - 1));
         }
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const unsigned kx = key_of(raw[j]);
-            R.key[j] = j * TR_THREADS + tid < nc ? (kx == 0 ? 1u : kx) : 0u;
+            R.key[j] = j * THREADS + tid < nc ? (kx == 0 ? 1u : kx) : 0u;
         }
     }
 
@@ -560,11 +332,11 @@ __device__ __forceinline__ void topk_rows_reg_body(const float* __restrict__ A, 
                 wc += mask_count(__ballot(above));
                 if (kx != 0 && !above && v >= lo) {
                     const unsigned pos = atomicAdd(&sh.ncand, 1u);
-                    if (pos < TK_CAND) cidx[pos] = (unsigned short)(j * TR_THREADS + tid);
+                    if (pos < TK_CAND) cidx[pos] = (unsigned short)(j * THREADS + tid);
                 }
                 if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
-            const int n_above = block_sum(sh, par, wc, lane, wave);
+            const int n_above = block_sum<TR_WAVES>(sh, par, wc, lane, wave);
             __syncthreads();
             const int n_cand = (int)sh.ncand;
             const int m = Rk - n_above;
@@ -578,7 +350,7 @@ __device__ __forceinline__ void topk_rows_reg_body(const float* __restrict__ A, 
             } else {
                 const int grp = tid >> 4, sub = tid & 15;
                 const double* gr = ex.G_rows + xrow * ex.ldg;
-                for (int a2 = grp; a2 < n_cand; a2 += TR_THREADS / 16) {
+                for (int a2 = grp; a2 < n_cand; a2 += THREADS / 16) {
                     const double* gc = ex.G_coh + (int64_t)cidx[a2] * ex.ldg;
                     double acc = 0.0;
                     for (int kk = sub; kk < ex.K; kk += 16) acc = fma(gr[kk], gc[kk], acc);
@@ -710,8 +482,8 @@ __device__ __forceinline__ void topk_rows_reg_body(const float* __restrict__ A, 
     auto override_bits = [&](int n, const unsigned short* cidx, const unsigned char* cabove, unsigned (&bits)[SELW]) {
         for (int a2 = 0; a2 < n; ++a2) {
             const int i = cidx[a2];
-            if ((i & (TR_THREADS - 1)) == tid) {
-                const int j = i / TR_THREADS;
+            if ((i & (THREADS - 1)) == tid) {
+                const int j = i / THREADS;
                 const unsigned bit = 1u << (j & 31);
 #pragma unroll
                 for (int w = 0; w < SELW; ++w)
@@ -742,7 +514,7 @@ __device__ __forceinline__ void topk_rows_reg_body(const float* __restrict__ A, 
         if (tid < 32) {  // first place of every class: exclusive scan of the class totals
             int tot = 0;
 #pragma unroll
-            for (int q2 = 0; q2 < 8; ++q2) tot += bank_cnt[q2][tid];
+            for (int q2 = 0; q2 < THREADS / 32; ++q2) tot += bank_cnt[q2][tid];
             int incl = tot;
 #pragma unroll
             for (int off = 1; off < 32; off <<= 1) {
@@ -763,12 +535,12 @@ __device__ __forceinline__ void topk_rows_reg_body(const float* __restrict__ A, 
                 const int j = 32 * w + __builtin_ctz(bits);
                 bits &= bits - 1;
                 const int dst = at < 0 ? at + k : at;
-                if (dst < k) ordered[dst] = (unsigned short)(j * TR_THREADS + tid);  // (always: exactly k are selected)
+                if (dst < k) ordered[dst] = (unsigned short)(j * THREADS + tid);  // (always: exactly k are selected)
                 ++at;
             }
         }
         __syncthreads();
-        for (int g = tid; g < groups; g += TR_THREADS)
+        for (int g = tid; g < groups; g += THREADS)
             reinterpret_cast<uint4*>(idx8)[(int64_t)g * ldi + row] = reinterpret_cast<const uint4*>(ordered)[g];
         return;
     }
@@ -792,13 +564,13 @@ __device__ __forceinline__ void topk_rows_reg_body(const float* __restrict__ A, 
         const unsigned long long m_sel = __ballot(sel);
         const int pos = (int)(base_of(basev, j) + lanes_below(m_sel));
         if (sel && pos < k) {
-            if (staged) stage[pos] = (unsigned short)(j * TR_THREADS + tid);
-            else idx8[((int64_t)(pos >> 3) * ldi + row) * 8 + (pos & 7)] = (uint16_t)(j * TR_THREADS + tid);
+            if (staged) stage[pos] = (unsigned short)(j * THREADS + tid);
+            else idx8[((int64_t)(pos >> 3) * ldi + row) * 8 + (pos & 7)] = (uint16_t)(j * THREADS + tid);
         }
     }
     if (staged) {
         __syncthreads();
-        for (int g = tid; g < groups; g += TR_THREADS)
+        for (int g = tid; g < groups; g += THREADS)
             reinterpret_cast<uint4*>(idx8)[(int64_t)g * ldi + row] = reinterpret_cast<const uint4*>(stage)[g];
     }
 }
@@ -806,37 +578,37 @@ __device__ __forceinline__ void topk_rows_reg_body(const float* __restrict__ A, 
 // The kernel is bound by instruction issue and its barriers: more resident waves help as long as the keys
 // still fit the registers that leaves.  Measured for 20 000-member rows (80 keys per thread): 7.3 ms per
 // three chunks at two waves per SIMD (what the compiler chooses on its own), 5.9 at three, 5.3 at four.
-template <int ITEMS>
-__global__ __launch_bounds__(TR_THREADS) void topk_rows_reg_kernel(const float* __restrict__ A, int64_t lda, int nc,
-                                                                   int k, int discard, uint16_t* __restrict__ idx8,
-                                                                   int64_t ldi, ExactSrc ex) {
-    topk_rows_reg_body<ITEMS>(A, lda, nc, k, discard, idx8, ldi, ex);
+template <int ITEMS, int THREADS>
+__global__ __launch_bounds__(THREADS) void topk_rows_reg_kernel(const float* __restrict__ A, int64_t lda, int nc,
+                                                                int k, int discard, uint16_t* __restrict__ idx8,
+                                                                int64_t ldi, ExactSrc ex) {
+    topk_rows_reg_body<ITEMS, THREADS>(A, lda, nc, k, discard, idx8, ldi, ex);
 }
-template <int ITEMS>
-__global__ __launch_bounds__(TR_THREADS) __attribute__((amdgpu_waves_per_eu(3))) void topk_rows_reg_kernel_w3(
+template <int ITEMS, int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3))) void topk_rows_reg_kernel_w3(
     const float* __restrict__ A, int64_t lda, int nc, int k, int discard, uint16_t* __restrict__ idx8, int64_t ldi,
     ExactSrc ex) {
-    topk_rows_reg_body<ITEMS>(A, lda, nc, k, discard, idx8, ldi, ex);
+    topk_rows_reg_body<ITEMS, THREADS>(A, lda, nc, k, discard, idx8, ldi, ex);
 }
-template <int ITEMS>
-__global__ __launch_bounds__(TR_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void topk_rows_reg_kernel_w4(
+template <int ITEMS, int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) void topk_rows_reg_kernel_w4(
     const float* __restrict__ A, int64_t lda, int nc, int k, int discard, uint16_t* __restrict__ idx8, int64_t ldi,
     ExactSrc ex) {
-    topk_rows_reg_body<ITEMS>(A, lda, nc, k, discard, idx8, ldi, ex);
+    topk_rows_reg_body<ITEMS, THREADS>(A, lda, nc, k, discard, idx8, ldi, ex);
 }
 
-template <int ITEMS>
+template <int ITEMS, int THREADS = TR_THREADS>
 void launch_topk_reg(const float* A, int64_t n_rows, int nc, int64_t lda, int k, int discard, uint16_t* idx_t,
                      int64_t ldi, const ExactSrc& ex, hipStream_t stream) {
     // as many waves per SIMD as the keys leave registers for without spilling
     if constexpr (ITEMS <= 80)
-        hipLaunchKernelGGL((topk_rows_reg_kernel_w4<ITEMS>), dim3((unsigned)n_rows), dim3(TR_THREADS), 0, stream, A,
-                           lda, nc, k, discard, idx_t, ldi, ex);
-    else if constexpr (ITEMS <= 96)
-        hipLaunchKernelGGL((topk_rows_reg_kernel_w3<ITEMS>), dim3((unsigned)n_rows), dim3(TR_THREADS), 0, stream, A,
-                           lda, nc, k, discard, idx_t, ldi, ex);
+        hipLaunchKernelGGL((topk_rows_reg_kernel_w4<ITEMS, THREADS>), dim3((unsigned)n_rows), dim3(THREADS), 0, stream,
+                           A, lda, nc, k, discard, idx_t, ldi, ex);
+    else if constexpr (ITEMS <= 96 && THREADS == 256)
+        hipLaunchKernelGGL((topk_rows_reg_kernel_w3<ITEMS, THREADS>), dim3((unsigned)n_rows), dim3(THREADS), 0, stream,
+                           A, lda, nc, k, discard, idx_t, ldi, ex);
     else
-        hipLaunchKernelGGL((topk_rows_reg_kernel<ITEMS>), dim3((unsigned)n_rows), dim3(TR_THREADS), 0, stream, A,
+        hipLaunchKernelGGL((topk_rows_reg_kernel<ITEMS, THREADS>), dim3((unsigned)n_rows), dim3(THREADS), 0, stream, A,
                            lda, nc, k, discard, idx_t, ldi, ex);
 }
 
@@ -1467,6 +1239,305 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
 #undef HYPMI_NEXT_LOAD
 #undef HYPMI_APPLY_PREFETCH
 
+// ---- segmented gather: cohorts whose rows do not fit LDS two at a time --------------------------------
+// The cohort is cut into S segments of seg_len members (a multiple of 32, so that a member keeps its LDS
+// bank class) that do fit with R = 2, the lists are partitioned by segment, and a workgroup walks its
+// lists once per segment with the moments of SG_NL lists per lane carried in registers.  Cost against an
+// undivided cohort: the lanes of a wave wait for the longest of their 64 list parts (about 1.15 x with two
+// segments, 1.2 x with three), and the rows are fetched once per SG_NL rounds of lists instead of once
+// per 64 or 128.
+//
+// Segmented lists (segment_lists_kernel): list q keeps its layout (groups of eight 16-bit entries, entry
+// j at seg8[((j >> 3) ldi + q) 8 + (j & 7)]), its members ordered by segment (stable: the bank order
+// inside a segment is the one the selection kernel produced) and stored as 1 + (member - segment start);
+// every segment's part is padded to whole groups with entries 0, which is the LDS entry that holds zeros.
+// gstart[s ldi + q] (s = 0 .. S) is the first group of segment s of list q.
+constexpr int SG_NL = 8;        // lists per lane of one workgroup (their moments: 4 R registers each)
+constexpr int SG_MAX_SEG = 8;
+
+__global__ __launch_bounds__(256) void segment_lists_kernel(const uint16_t* __restrict__ idx8, int64_t ldi, int k,
+                                                            int64_t Q, int S, int seg_len,
+                                                            uint16_t* __restrict__ seg8,
+                                                            uint16_t* __restrict__ gstart) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;  // wave-uniform
+    auto entry = [&](int j) -> unsigned { return idx8[(((int64_t)(j >> 3)) * ldi + q) * 8 + (j & 7)]; };
+    auto seg_of = [&](unsigned c) -> int {
+        int s = 0;
+        for (int b = 1; b < S; ++b) s += c >= (unsigned)(b * seg_len) ? 1 : 0;
+        return s;
+    };
+    int cnt[SG_MAX_SEG];
+#pragma unroll
+    for (int s = 0; s < SG_MAX_SEG; ++s) cnt[s] = 0;
+    for (int j0 = 0; j0 < k; j0 += 64) {
+        const int j = j0 + lane;
+        const int sg = j < k ? seg_of(entry(j)) : -1;
+#pragma unroll
+        for (int s = 0; s < SG_MAX_SEG; ++s) cnt[s] += __popcll(__ballot(sg == s));
+    }
+    int pos[SG_MAX_SEG];  // next entry position of every segment
+    int g = 0;
+#pragma unroll
+    for (int s = 0; s < SG_MAX_SEG; ++s) {
+        if (s <= S && lane == 0) gstart[(int64_t)s * ldi + q] = (uint16_t)g;
+        pos[s] = 8 * g;
+        if (s < S) {
+            // the padding of this segment's last group
+            const int p = 8 * g + cnt[s] + lane;
+            g += (cnt[s] + 7) >> 3;
+            if (lane < 8 && p < 8 * g) seg8[(((int64_t)(p >> 3)) * ldi + q) * 8 + (p & 7)] = 0;
+        }
+    }
+    if (S == SG_MAX_SEG && lane == 0) gstart[(int64_t)S * ldi + q] = (uint16_t)g;
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (int j0 = 0; j0 < k; j0 += 64) {
+        const int j = j0 + lane;
+        const unsigned c = j < k ? entry(j) : 0u;
+        const int sg = j < k ? seg_of(c) : -1;
+#pragma unroll
+        for (int s = 0; s < SG_MAX_SEG; ++s) {
+            const uint64_t m = __ballot(sg == s);
+            if (sg == s) {
+                const int p = pos[s] + __popcll(m & below);
+                seg8[(((int64_t)(p >> 3)) * ldi + q) * 8 + (p & 7)] = (uint16_t)(c - (unsigned)(s * seg_len) + 1u);
+            }
+            pos[s] += __popcll(m);
+        }
+    }
+}
+
+// MODE as in gather_pivot_kernel (0: statistics stored, as pairs when istd == nullptr; 1 / 2: normalised
+// scores stored, the other side's statistics in two arrays / as pairs).  R = 2.
+template <int MODE>
+__global__ __launch_bounds__(GS_THREADS) void gather_seg_kernel(
+    const float* __restrict__ X, int64_t ldx, int64_t n_rows, int nc, const uint16_t* __restrict__ seg8,
+    const uint16_t* __restrict__ gstart, int64_t ldi, unsigned seg_bytes, const uint16_t* __restrict__ idx8, int k,
+    int64_t Q, int S, int seg_len, float floor_, float* __restrict__ mean, float* __restrict__ istd, int64_t ldo,
+    ApplyArgs ap) {
+    constexpr int R = 2;
+    constexpr bool APPLY = MODE != 0, PAIRS = MODE == 2;
+    extern __shared__ __attribute__((aligned(16))) float xr[];  // entry 0: zeros; entry 1 + c: member c of the segment
+    float* red = xr + (size_t)(seg_len + 1) * R;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int64_t grp = blockIdx.x;
+    if (APPLY) {  // the grid is padded to whole sets of 8 x GP_XCD_GROUPS row groups
+        const int64_t slot = grp >> 3, xcd = grp & 7;
+        grp = ((slot / GP_XCD_GROUPS) * 8 + xcd) * GP_XCD_GROUPS + slot % GP_XCD_GROUPS;
+        if (grp * R >= n_rows) return;
+    }
+    const int64_t r0 = grp * R;
+    const int64_t q0 = (int64_t)blockIdx.y * (SG_NL * GS_THREADS);
+    const int64_t q1 = (q0 + SG_NL * GS_THREADS < Q) ? q0 + SG_NL * GS_THREADS : Q;
+    if (q0 >= q1) return;
+    const int nl = (int)((q1 - q0 + GS_THREADS - 1) / GS_THREADS);  // rounds of lists in this block
+    // pivot of a row: mean of its first min(nc, 1024) entries, as in gather_pivot_kernel
+    float rowpiv[R];
+    {
+        const int ns = nc < GS_THREADS ? nc : GS_THREADS;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            float v = (r0 + rr < n_rows && tid < ns) ? X[(r0 + rr) * ldx + tid] : 0.f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0) red[rr * 16 + wave] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < GS_THREADS / 64; ++w) sum += red[rr * 16 + w];
+            rowpiv[rr] = sum / (float)ns;
+        }
+    }
+    const unsigned xbase = __builtin_amdgcn_readfirstlane(lds_address(xr));
+    const bool vec_ok = ldx % 4 == 0 && reinterpret_cast<uintptr_t>(X) % 16 == 0;  // uniform (seg_len % 32 == 0)
+    // moments of the lane's lists: [0] is the list being walked, the arrays rotate at the end of every list
+    float s1[SG_NL][R], s2[SG_NL][R];
+#pragma unroll
+    for (int l = 0; l < SG_NL; ++l)
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) s1[l][rr] = s2[l][rr] = 0.f;
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const unsigned step = (unsigned)(ldi * 16);  // bytes from a group of a list to its next (checked at launch)
+    for (int s = 0; s < S; ++s) {
+        __syncthreads();  // the previous segment (or the pivot scratch) is no longer read
+        const int base = s * seg_len;
+        const int len = nc - base < seg_len ? nc - base : seg_len;
+        if (vec_ok) {
+            typedef typename LdsVec<4>::type f4;
+            const int len4 = len >> 2;
+            for (int c4 = tid; c4 < len4; c4 += GS_THREADS) {
+                f4 v[R];
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                    v[rr] = f4{0.f, 0.f, 0.f, 0.f};
+                    if (r0 + rr < n_rows)
+                        v[rr] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(X + (r0 + rr) * ldx + base) + c4);
+                }
+                float2* dst = reinterpret_cast<float2*>(xr) + 1 + 4 * c4;
+                dst[0] = make_float2(v[0].x - rowpiv[0], v[1].x - rowpiv[1]);
+                dst[1] = make_float2(v[0].y - rowpiv[0], v[1].y - rowpiv[1]);
+                dst[2] = make_float2(v[0].z - rowpiv[0], v[1].z - rowpiv[1]);
+                dst[3] = make_float2(v[0].w - rowpiv[0], v[1].w - rowpiv[1]);
+            }
+            for (int c = 4 * len4 + tid; c < len; c += GS_THREADS)
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr)
+                    xr[(size_t)(c + 1) * R + rr] = r0 + rr < n_rows ? X[(r0 + rr) * ldx + base + c] - rowpiv[rr] : 0.f;
+        } else {
+            for (int c = tid; c < len; c += GS_THREADS)
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr)
+                    xr[(size_t)(c + 1) * R + rr] = r0 + rr < n_rows ? X[(r0 + rr) * ldx + base + c] - rowpiv[rr] : 0.f;
+        }
+        if (tid < R) xr[tid] = 0.f;
+        __syncthreads();
+        // group range of the lane's first list in this segment; those of the next list are fetched a list ahead
+        auto range_of = [&](int l, unsigned& first, int& count) {
+            const int64_t q = q0 + (int64_t)l * GS_THREADS + tid;
+            first = 0;
+            count = 0;
+            if (l < nl && q < q1) {
+                first = gstart[(int64_t)s * ldi + q];
+                count = (int)gstart[(int64_t)(s + 1) * ldi + q] - (int)first;
+            }
+        };
+        unsigned g_first, g_first_next;
+        int n_grp, n_grp_next;
+        range_of(0, g_first, n_grp);
+        for (int l = 0; l < SG_NL; ++l) {
+            range_of(l + 1, g_first_next, n_grp_next);
+            int nmax = n_grp;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const int o = __shfl_xor(nmax, off, 64);
+                nmax = o > nmax ? o : nmax;
+            }
+            nmax = __builtin_amdgcn_readfirstlane(nmax);
+            // byte offset of the lane's first group of this part (the whole list array is one buffer)
+            const unsigned voff0 = (unsigned)((((int64_t)g_first * ldi) + q0 + (int64_t)l * GS_THREADS + tid) * 16);
+            uint4 ring[GP_RING];
+            // group i of the part: lanes whose part is shorter read past the end of the buffer and get zeros,
+            // i.e. eight times the entry of zeros
+#define HYPMI_SEG_LOAD(dst, I)                                                                            \
+    {                                                                                                     \
+        const unsigned vo_ = (I) < n_grp ? voff0 + (unsigned)(I) * step : 0xfffffff0u;                   \
+        const v4u w_ = __builtin_amdgcn_raw_buffer_load_b128(                                             \
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(seg8), 0, seg_bytes, 0x00020000), vo_, 0, 0); \
+        dst = make_uint4(w_[0], w_[1], w_[2], w_[3]);                                                     \
+    }
+#define HYPMI_SEG_GROUP(D, RELOAD, I)                                                                     \
+    {                                                                                                     \
+        unsigned a[8];                                                                                    \
+        a[0] = entry_addr<R, 0>(ring[D].x, xbase); a[1] = entry_addr<R, 1>(ring[D].x, xbase);             \
+        a[2] = entry_addr<R, 0>(ring[D].y, xbase); a[3] = entry_addr<R, 1>(ring[D].y, xbase);             \
+        a[4] = entry_addr<R, 0>(ring[D].z, xbase); a[5] = entry_addr<R, 1>(ring[D].z, xbase);             \
+        a[6] = entry_addr<R, 0>(ring[D].w, xbase); a[7] = entry_addr<R, 1>(ring[D].w, xbase);             \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        if (RELOAD) HYPMI_SEG_LOAD(ring[D], I)                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        typename LdsVec<R>::type val[8];                                                                  \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) val[e] = lds_vec<R>(a[e]);                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                     \
+            _Pragma("unroll") for (int rr = 0; rr < R; ++rr)                                              \
+                moment_step(s1[0][rr], s2[0][rr], lds_vec_elem<R>(val[e], rr));                           \
+    }
+            if (nmax > 0) {
+#pragma unroll
+                for (int d = 0; d < GP_RING; ++d) HYPMI_SEG_LOAD(ring[d], d)
+                int i = 0;
+                for (; i + GP_RING <= nmax; i += GP_RING) {
+                    HYPMI_SEG_GROUP(0, true, i + 4)
+                    HYPMI_SEG_GROUP(1, true, i + 5)
+                    HYPMI_SEG_GROUP(2, true, i + 6)
+                    HYPMI_SEG_GROUP(3, true, i + 7)
+                }
+                if (i < nmax) HYPMI_SEG_GROUP(0, false, 0)
+                if (i + 1 < nmax) HYPMI_SEG_GROUP(1, false, 0)
+                if (i + 2 < nmax) HYPMI_SEG_GROUP(2, false, 0)
+            }
+#undef HYPMI_SEG_GROUP
+#undef HYPMI_SEG_LOAD
+            // the next list's moments move to the front
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const float t1 = s1[0][rr], t2 = s2[0][rr];
+#pragma unroll
+                for (int m = 0; m + 1 < SG_NL; ++m) {
+                    s1[m][rr] = s1[m + 1][rr];
+                    s2[m][rr] = s2[m + 1][rr];
+                }
+                s1[SG_NL - 1][rr] = t1;
+                s2[SG_NL - 1][rr] = t2;
+            }
+            g_first = g_first_next;
+            n_grp = n_grp_next;
+        }
+    }
+    // after S x SG_NL rotations the moments of list l are back in place l
+    const float inv_k = 1.0f / (float)k, floor2 = floor_ * floor_, inv_floor = 1.0f / floor_;
+    const uint4* base = reinterpret_cast<const uint4*>(idx8);
+#pragma unroll
+    for (int l = 0; l < SG_NL; ++l) {
+        const int64_t q = q0 + (int64_t)l * GS_THREADS + tid;
+        if (l >= nl || q >= q1) continue;
+        float lp[R], m1[R], m2[R];
+        bool redo = false;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            lp[rr] = rowpiv[rr];
+            m1[rr] = s1[l][rr];
+            m2[rr] = s2[l][rr];
+            const float md = m1[rr] * inv_k, ms = m2[rr] * inv_k;
+            redo |= fmaf(-md, md, ms) * GP_AMP < ms;  // false for NaN: those stay NaN
+        }
+        if (redo) {  // a selection far from the row pivot: again around the list's own first member
+            const ShiftedMoments<R> m = list_moments_shifted<R>(X, ldx, r0, n_rows, base + q, ldi, k);
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                lp[rr] = m.piv[rr];
+                m1[rr] = m.s1[rr];
+                m2[rr] = m.s2[rr];
+            }
+            atomicAdd(&g_gather_redo, 1ull);
+        }
+        typename LdsVec<2 * R>::type pmi;
+        typename LdsVec<R>::type pm, pi;
+        if (PAIRS) {
+            pmi = load_pairs<R>(ap.mt + (q * ap.ldt + r0) * 2);
+        } else if (APPLY) {
+            pm = *reinterpret_cast<const typename LdsVec<R>::type*>(ap.mt + q * ap.ldt + r0);
+            pi = *reinterpret_cast<const typename LdsVec<R>::type*>(ap.it + q * ap.ldt + r0);
+        }
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            if (r0 + rr >= n_rows) continue;
+            const float md = m1[rr] * inv_k;
+            float var = fmaf(-md, md, m2[rr] * inv_k);
+            var = var > 0.f ? var : (var == var ? 0.f : var);  // NaN stays NaN
+            const float is = var < floor2 ? inv_floor : __builtin_amdgcn_rsqf(var);
+            const float m = fmaf(m1[rr], inv_k, lp[rr]);
+            if (PAIRS) {
+                const float sc = __builtin_nontemporal_load(ap.S + (r0 + rr) * ap.lds + q);
+                ap.out[(r0 + rr) * ap.ldo + q] = asnorm_value(sc, m, is, pmi[2 * rr], pmi[2 * rr + 1]);
+            } else if (APPLY) {
+                const float sc = __builtin_nontemporal_load(ap.S + (r0 + rr) * ap.lds + q);
+                ap.out[(r0 + rr) * ap.ldo + q] =
+                    asnorm_value(sc, m, is, lds_vec_elem<R>(pm, rr), lds_vec_elem<R>(pi, rr));
+            } else if (istd == nullptr) {
+                reinterpret_cast<float2*>(mean)[(r0 + rr) * ldo + q] = make_float2(m, is);
+            } else {
+                mean[(r0 + rr) * ldo + q] = m;
+                istd[(r0 + rr) * ldo + q] = is;
+            }
+        }
+    }
+}
+
 // out[e, t] = ((S - mz[e,t]) * iz[e,t] + (S - mt[t,e]) * it[t,e]) / sqrt(2); the T-part statistics
 // arrive transposed and go through a 32 x 33 LDS tile.
 __global__ __launch_bounds__(256) void asnorm_apply_kernel(const float* __restrict__ S, int64_t lds_,
@@ -1592,7 +1663,9 @@ __global__ __launch_bounds__(256) void mask_zero_kernel(float* __restrict__ X, i
 }  // namespace
 
 extern "C" int64_t hypmi_topk_workspace_bytes(int64_t n_rows, int nc) {
-    return nc <= TR_MAX_NC ? 0 : n_rows * (int64_t)nc * 4;
+    (void)n_rows;
+    (void)nc;
+    return 0;  // every cohort the 16-bit lists can name is selected from registers
 }
 
 extern "C" int64_t hypmi_topk_list_bytes(int k, int64_t ldi) {
@@ -1623,10 +1696,9 @@ extern "C" int hypmi_topk_rows(const float* A, int64_t n_rows, int nc, int64_t l
         } else {
             HYPMI_REQUIRE(exact->bnd_rows && exact->todo && exact->todo_count,
                           "topk_rows: mode 3 needs the rows' bounds and the list of rows to fill");
-            HYPMI_REQUIRE(nc <= TR_MAX_NC, "topk_rows: mode 3 is for cohorts of up to %d members", TR_MAX_NC);
+        
         }
-        HYPMI_REQUIRE(!exact->row_map || (exact->mode == 2 && nc <= TR_MAX_NC),
-                      "topk_rows: a row map goes with mode 2 and cohorts of up to %d members", TR_MAX_NC);
+        HYPMI_REQUIRE(!exact->row_map || exact->mode == 2, "topk_rows: a row map goes with mode 2");
         ex.mode = exact->mode;
         ex.A64 = exact->A64;
         ex.lda64 = exact->lda64;
@@ -1644,20 +1716,26 @@ extern "C" int hypmi_topk_rows(const float* A, int64_t n_rows, int nc, int64_t l
         ex.todo_count = exact->todo_count;
     }
     if (n_rows == 0) return HYPMI_OK;
-    if (nc <= TR_MAX_NC) {  // keys in registers
+    // Threads per row: 256 while a thread's keys leave registers for three or four waves per SIMD, then 512
+    // (up to 80 keys each still run four waves per SIMD; 65 536 rows of 40 960 members: 7.6 ms
+    // with 160 keys in each of 256 threads, one wave per SIMD; 3.6 ms with 80 in each of 512).  More threads
+    // at the same keys per thread do not pay: 20 000 members take 1.33 ms with 256 threads, 1.81 with 512.
+    if (nc <= 96 * 256) {
         const int items = (nc + TR_THREADS - 1) / TR_THREADS;
 #define HYPMI_TOPK_CASE(N) \
     if (items <= N) { launch_topk_reg<N>(A, n_rows, nc, lda, k, discard, idx_t, ldi, ex, stream); } else
         HYPMI_TOPK_CASE(4) HYPMI_TOPK_CASE(8) HYPMI_TOPK_CASE(16) HYPMI_TOPK_CASE(32) HYPMI_TOPK_CASE(48)
-        HYPMI_TOPK_CASE(64) HYPMI_TOPK_CASE(80) HYPMI_TOPK_CASE(96) HYPMI_TOPK_CASE(128)
-        { launch_topk_reg<TR_MAX_ITEMS>(A, n_rows, nc, lda, k, discard, idx_t, ldi, ex, stream); }
+        HYPMI_TOPK_CASE(64) HYPMI_TOPK_CASE(80)
+        { launch_topk_reg<96>(A, n_rows, nc, lda, k, discard, idx_t, ldi, ex, stream); }
 #undef HYPMI_TOPK_CASE
-    } else {  // keys in a global workspace, radix select with LDS histograms
-        HYPMI_REQUIRE(workspace && workspace_bytes >= n_rows * (int64_t)nc * 4,
-                      "topk_rows: cohort of %d needs a %lld-byte workspace", nc,
-                      (long long)(n_rows * (int64_t)nc * 4));
-        hipLaunchKernelGGL(topk_rows_kernel<false>, dim3((unsigned)n_rows), dim3(TK_THREADS), 368 * 4,
-                           stream, A, lda, nc, k, discard, idx_t, ldi, static_cast<unsigned*>(workspace), ex);
+    } else if (nc <= 64 * 512) {
+        launch_topk_reg<64, 512>(A, n_rows, nc, lda, k, discard, idx_t, ldi, ex, stream);
+    } else if (nc <= 80 * 512) {
+        launch_topk_reg<80, 512>(A, n_rows, nc, lda, k, discard, idx_t, ldi, ex, stream);
+    } else if (nc <= 96 * 512) {  // (1024 threads with 48 or 64 keys each are no faster than these two)
+        launch_topk_reg<96, 512>(A, n_rows, nc, lda, k, discard, idx_t, ldi, ex, stream);
+    } else if (nc <= TR_MAX_NC) {
+        launch_topk_reg<128, 512>(A, n_rows, nc, lda, k, discard, idx_t, ldi, ex, stream);
     }
     HYPMI_HIP(hipGetLastError());
     return HYPMI_OK;
@@ -1864,6 +1942,102 @@ extern "C" int hypmi_gather_apply_pairs(const float* X, int64_t n_rows, int nc, 
                                          stream, ap);
     return launch_gather_pivot<1, 2>(X, n_rows, nc, ldx, idx_t, ldi, k, n_lists, std_floor, nullptr, nullptr, 0,
                                      stream, ap);
+}
+
+namespace {
+constexpr int SG_SEG_CAP = ((MAX_LDS_BYTES / 4 - GP_SCRATCH_FLOATS) / 2 - 1) / 32 * 32;  // members per segment (R = 2)
+
+// segments, members per segment and list groups for a cohort of nc members and lists of k; false when the
+// undivided kernel takes the cohort two rows at a time (or nothing here applies)
+inline bool seg_plan(int nc, int k, int* n_seg, int* seg_len, int* groups) {
+    if (nc <= 0 || nc > 65535 || k <= 0 || pivot_lds_bytes(nc, 2) <= MAX_LDS_BYTES) return false;
+    const int S = (nc + SG_SEG_CAP - 1) / SG_SEG_CAP;
+    if (S > SG_MAX_SEG) return false;
+    *n_seg = S;
+    *seg_len = (int)round_up((nc + S - 1) / S, 32);
+    *groups = (k + 7) / 8 + S;
+    return true;
+}
+
+template <int MODE>
+int launch_gather_seg(const float* X, int64_t n_rows, int nc, int64_t ldx, const uint16_t* idx8,
+                      const uint16_t* seg8, const uint16_t* gstart, int64_t ldi, int k, int64_t n_lists,
+                      float std_floor, float* mean, float* istd, int64_t ldo, hipStream_t stream,
+                      const ApplyArgs& ap = ApplyArgs{}) {
+    int S, seg_len, groups_per_list;
+    HYPMI_REQUIRE(seg_plan(nc, k, &S, &seg_len, &groups_per_list),
+                  "gather (segmented): a cohort of %d does not take the segmented kernel", nc);
+    const int64_t seg_bytes = (int64_t)groups_per_list * ldi * 16;
+    HYPMI_REQUIRE(seg_bytes <= 0xffffff00LL, "gather (segmented): %lld bytes of lists exceed one buffer",
+                  (long long)seg_bytes);
+    const int64_t lds_need = round_up(((int64_t)(seg_len + 1) * 2 + GP_SCRATCH_FLOATS) * 4, 16);
+    HYPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_seg_kernel<MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
+    const int64_t groups = (n_rows + 1) / 2;
+    const int64_t gx = MODE != 0 ? round_up(groups, 8 * GP_XCD_GROUPS) : groups;
+    const int64_t gy = (n_lists + SG_NL * GS_THREADS - 1) / (SG_NL * GS_THREADS);
+    HYPMI_REQUIRE(gx <= 0x7fffffffLL && gy <= 65535, "gather (segmented): too many rows or lists");
+    hipLaunchKernelGGL((gather_seg_kernel<MODE>), dim3((unsigned)gx, (unsigned)gy), dim3(GS_THREADS), lds_need,
+                       stream, X, ldx, n_rows, nc, seg8, gstart, ldi, (unsigned)seg_bytes, idx8, k, n_lists, S, seg_len,
+                       std_floor, mean, istd, ldo, ap);
+    HYPMI_HIP(hipGetLastError());
+    return HYPMI_OK;
+}
+}  // namespace
+
+extern "C" int hypmi_gather_seg_plan(int nc, int k, int* n_seg, int* seg_len, int* groups) {
+    int a = 0, b = 0, c = 0;
+    const bool ok = seg_plan(nc, k, &a, &b, &c);
+    if (n_seg) *n_seg = ok ? a : 0;
+    if (seg_len) *seg_len = ok ? b : 0;
+    if (groups) *groups = ok ? c : 0;
+    return ok ? 1 : 0;
+}
+
+extern "C" int hypmi_segment_lists(const uint16_t* idx_t, int64_t ldi, int k, int64_t n_lists, int nc,
+                                   uint16_t* seg_idx, uint16_t* gstart, void* stream_) {
+    HYPMI_REQUIRE(idx_t && seg_idx && gstart, "segment_lists: null pointer");
+    HYPMI_REQUIRE(n_lists >= 0 && ldi >= n_lists && aligned16(idx_t) && aligned16(seg_idx), "segment_lists: bad shape");
+    int S, seg_len, groups;
+    HYPMI_REQUIRE(seg_plan(nc, k, &S, &seg_len, &groups), "segment_lists: a cohort of %d is not segmented", nc);
+    if (n_lists == 0) return HYPMI_OK;
+    hipLaunchKernelGGL(segment_lists_kernel, dim3((unsigned)((n_lists + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), idx_t, ldi, k, n_lists, S, seg_len, seg_idx, gstart);
+    HYPMI_HIP(hipGetLastError());
+    return HYPMI_OK;
+}
+
+extern "C" int hypmi_gather_stats_seg(const float* X, int64_t n_rows, int nc, int64_t ldx, const uint16_t* idx_t,
+                                      const uint16_t* seg_idx, const uint16_t* gstart, int64_t ldi, int k,
+                                      int64_t n_lists, float std_floor, float* mean, float* istd, int64_t ldo,
+                                      void* stream_) {
+    HYPMI_REQUIRE(X && idx_t && seg_idx && gstart && mean, "gather_stats_seg: null pointer");
+    HYPMI_REQUIRE(n_rows >= 0 && ldx >= nc && k > 0 && n_lists >= 0 && ldi >= n_lists && ldo >= n_lists,
+                  "gather_stats_seg: bad shape");
+    HYPMI_REQUIRE(aligned16(idx_t) && aligned16(seg_idx), "gather_stats_seg: index lists must be 16-byte aligned");
+    HYPMI_REQUIRE(istd != nullptr || reinterpret_cast<uintptr_t>(mean) % 8 == 0,
+                  "gather_stats_seg: paired statistics must be 8-byte aligned");
+    if (n_rows == 0 || n_lists == 0) return HYPMI_OK;
+    return launch_gather_seg<0>(X, n_rows, nc, ldx, idx_t, seg_idx, gstart, ldi, k, n_lists, std_floor, mean, istd,
+                                ldo, static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int hypmi_gather_apply_seg(const float* X, int64_t n_rows, int nc, int64_t ldx, const uint16_t* idx_t,
+                                      const uint16_t* seg_idx, const uint16_t* gstart, int64_t ldi, int k,
+                                      int64_t n_lists, float std_floor, const float* S, int64_t lds_,
+                                      const float* stats_t, int64_t ldt, float* out, int64_t ldo, void* stream_) {
+    HYPMI_REQUIRE(X && idx_t && seg_idx && gstart && S && stats_t && out, "gather_apply_seg: null pointer");
+    HYPMI_REQUIRE(n_rows >= 0 && ldx >= nc && k > 0 && n_lists >= 0 && ldi >= n_lists && lds_ >= n_lists &&
+                      ldo >= n_lists && ldt >= n_rows,
+                  "gather_apply_seg: bad shape");
+    HYPMI_REQUIRE(aligned16(idx_t) && aligned16(seg_idx), "gather_apply_seg: index lists must be 16-byte aligned");
+    HYPMI_REQUIRE(ldt % 2 == 0 && ldt >= round_up(n_rows, 2) && reinterpret_cast<uintptr_t>(stats_t) % 16 == 0,
+                  "gather_apply_seg: T-part statistics need an even leading dimension (in pairs) that covers the "
+                  "rows rounded up to it, and 16-byte alignment");
+    if (n_rows == 0 || n_lists == 0) return HYPMI_OK;
+    const ApplyArgs ap = {S, lds_, stats_t, nullptr, ldt, out, ldo};
+    return launch_gather_seg<2>(X, n_rows, nc, ldx, idx_t, seg_idx, gstart, ldi, k, n_lists, std_floor, nullptr,
+                                nullptr, 0, static_cast<hipStream_t>(stream_), ap);
 }
 
 extern "C" int hypmi_gather_redo_count(unsigned long long* count, int reset) {

@@ -100,6 +100,56 @@ def lists_to_numpy(idx, k):
     return a.transpose(1, 0, 2).reshape(a.shape[1], -1)[:, :k]
 
 
+class SegLists:
+    """Top-k lists partitioned by cohort segment for the statistics kernels that take the cohort in
+    pieces (cohorts whose rows do not fit LDS two at a time, see hypmi_gather_seg_plan): the lists as
+    selected (`idx`), the partitioned copy (`seg`, members as 1 + offset in their segment) and the first
+    group of every segment of every list (`gstart`)."""
+
+    def __init__(self, idx, seg, gstart, k, nc, n_lists):
+        self.idx, self.seg, self.gstart, self.k, self.nc, self.n_lists = idx, seg, gstart, k, nc, n_lists
+
+
+def seg_plan(nc, k):
+    """(segments, members per segment, groups per list) when a cohort of nc members is taken in segments,
+    else None (it fits LDS two rows at a time, or has more than 65 535 members)."""
+    import ctypes
+
+    a, b, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    if _lib.load().hypmi_gather_seg_plan(int(nc), int(k), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)):
+        return a.value, b.value, c.value
+    return None
+
+
+def segment_lists(idx, k, nc, n_lists):
+    """SegLists of grouped lists `idx` (or of a range of them, `idx[:, q0:q1]`).  Kept on the tensor
+    object: the enrolment side's lists are partitioned once and used for every chunk of tests."""
+    torch = engine.require_gpu()
+    cached = getattr(idx, "_hypmi_seg", None)
+    if cached is not None and (cached.k, cached.nc, cached.n_lists) == (k, nc, n_lists):
+        return cached
+    S, _, groups = seg_plan(nc, k)
+    assert idx.stride(2) == 1 and idx.stride(1) == 8 and idx.shape[1] >= n_lists
+    ldi = idx.stride(0) // 8
+    seg = torch.empty((groups, ldi, 8), dtype=torch.int16, device=idx.device)
+    gstart = torch.empty((S + 1, ldi), dtype=torch.int16, device=idx.device)
+    _lib.check(_lib.load().hypmi_segment_lists(engine._ptr(idx), ldi, int(k), n_lists, int(nc), engine._ptr(seg),
+                                               engine._ptr(gstart), engine.stream_ptr()))
+    sl = SegLists(idx, seg, gstart, k, nc, n_lists)
+    try:
+        idx._hypmi_seg = sl
+    except AttributeError:
+        pass
+    return sl
+
+
+def _stats_ld(n_lists, pairs):
+    ld = engine.round_up(max(n_lists, 1), 4)
+    if ld % (256 if pairs else 512) == 0:
+        ld += 16 if pairs else 32  # read down its columns as well: no stride that maps a column to one memory channel
+    return ld
+
+
 def gather_stats(X, mask_u8, idx, n_lists, std_floor, k):
     """mean / inverse std of X[r, list_q] for every row r and list q: two device [rows, lists].
     idx: grouped lists as topk_rows makes them, or a range of their lists (`idx[:, q0:q1]`)."""
@@ -107,11 +157,16 @@ def gather_stats(X, mask_u8, idx, n_lists, std_floor, k):
     lib = _lib.load()
     n, nc = X.shape
     assert idx.stride(2) == 1 and idx.stride(1) == 8 and idx.shape[1] >= n_lists
-    ld = engine.round_up(max(n_lists, 1), 4)
-    if ld % 512 == 0:
-        ld += 32  # the statistics are also read down their columns: no stride that maps a column to one memory channel
+    ld = _stats_ld(n_lists, False)
     mean = torch.empty((n, ld), dtype=torch.float32, device=X.device)
     istd = torch.empty((n, ld), dtype=torch.float32, device=X.device)
+    if mask_u8 is None and seg_plan(nc, k) is not None:
+        sl = segment_lists(idx, k, nc, n_lists)
+        _lib.check(lib.hypmi_gather_stats_seg(engine._ptr(X), n, nc, X.stride(0), engine._ptr(idx), engine._ptr(sl.seg),
+                                              engine._ptr(sl.gstart), idx.stride(0) // 8, int(k), n_lists,
+                                              float(std_floor), engine._ptr(mean), engine._ptr(istd), ld,
+                                              engine.stream_ptr()))
+        return mean, istd, ld
     _lib.check(lib.hypmi_gather_stats(engine._ptr(X), n, nc, X.stride(0),
                                       engine._ptr(mask_u8) if mask_u8 is not None else None,
                                       mask_u8.stride(0) if mask_u8 is not None else 0,
@@ -127,10 +182,15 @@ def gather_stats_pairs(X, idx, n_lists, std_floor, k):
     torch = engine.require_gpu()
     n, nc = X.shape
     assert idx.stride(2) == 1 and idx.stride(1) == 8 and idx.shape[1] >= n_lists
-    ld = engine.round_up(max(n_lists, 1), 4)
-    if ld % 256 == 0:
-        ld += 16  # read down its columns as well: no stride that maps a column to one memory channel
+    ld = _stats_ld(n_lists, True)
     stats = torch.empty((n, ld, 2), dtype=torch.float32, device=X.device)
+    if seg_plan(nc, k) is not None:
+        sl = segment_lists(idx, k, nc, n_lists)
+        _lib.check(_lib.load().hypmi_gather_stats_seg(engine._ptr(X), n, nc, X.stride(0), engine._ptr(idx),
+                                                      engine._ptr(sl.seg), engine._ptr(sl.gstart), idx.stride(0) // 8,
+                                                      int(k), n_lists, float(std_floor), engine._ptr(stats), None, ld,
+                                                      engine.stream_ptr()))
+        return stats, ld
     _lib.check(_lib.load().hypmi_gather_stats_pairs(engine._ptr(X), n, nc, X.stride(0), engine._ptr(idx),
                                                     idx.stride(0) // 8, int(k), n_lists, float(std_floor),
                                                     engine._ptr(stats), ld, engine.stream_ptr()))
@@ -143,6 +203,14 @@ def gather_apply_pairs(X, idx, n_lists, std_floor, k, S, stats_t, ldt, out):
     assert idx.stride(2) == 1 and idx.stride(1) == 8 and idx.shape[1] >= n_lists
     assert S.shape[0] == n and S.shape[1] >= n_lists and out.shape[0] == n and out.shape[1] >= n_lists
     assert stats_t.shape[0] >= n_lists and ldt >= n
+    if seg_plan(nc, k) is not None:
+        sl = segment_lists(idx, k, nc, n_lists)
+        _lib.check(_lib.load().hypmi_gather_apply_seg(engine._ptr(X), n, nc, X.stride(0), engine._ptr(idx),
+                                                      engine._ptr(sl.seg), engine._ptr(sl.gstart), idx.stride(0) // 8,
+                                                      int(k), n_lists, float(std_floor), engine._ptr(S), S.stride(0),
+                                                      engine._ptr(stats_t), ldt, engine._ptr(out), out.stride(0),
+                                                      engine.stream_ptr()))
+        return out
     _lib.check(_lib.load().hypmi_gather_apply_pairs(engine._ptr(X), n, nc, X.stride(0), engine._ptr(idx),
                                                     idx.stride(0) // 8, int(k), n_lists, float(std_floor),
                                                     engine._ptr(S), S.stride(0), engine._ptr(stats_t), ldt,
@@ -151,8 +219,14 @@ def gather_apply_pairs(X, idx, n_lists, std_floor, k, S, stats_t, ldt, out):
 
 
 def gather_apply_supported(nc, n_rows):
-    """Whether gather_apply can run for a cohort of nc members (its rows have to fit in LDS)."""
+    """Whether gather_apply (the other side's statistics in two arrays) can run for a cohort of nc members:
+    its rows have to fit in LDS undivided."""
     return bool(_lib.load().hypmi_gather_apply_supported(int(nc), int(n_rows)))
+
+
+def gather_pairs_supported(nc, n_rows, k):
+    """Whether gather_stats_pairs / gather_apply_pairs can run: the rows fit in LDS, undivided or in segments."""
+    return gather_apply_supported(nc, n_rows) or seg_plan(nc, k) is not None
 
 
 def gather_apply(X, idx, n_lists, std_floor, k, S, mt, it, ldt, out):
@@ -189,11 +263,12 @@ def adapt_s_norm_device(S, A_ec, A_tc, nbest, nbest_discard, mask_ec=None, mask_
         return out[:, :nt]
     t_idx = topk_rows(A_tc, k, int(nbest_discard), exact_tc)  # per test: cohort ranked by coh-vs-test
     e_idx = topk_rows(A_ec, k, int(nbest_discard), exact_ec)  # per enrol: cohort ranked by enr-vs-coh
-    fused = mask_ec is None and gather_apply_supported(nc, ne)
-    if fused and mask_tc is None:  # T-part mean and 1 / std side by side: one line per list in the Z part
+    if mask_ec is None and mask_tc is None and gather_pairs_supported(nc, min(ne, nt), k):
+        # T-part mean and 1 / std side by side: one line per list in the Z part
         st, ldt = gather_stats_pairs(A_tc, e_idx, ne, std_floor, k)  # [test, enrol, 2]
         gather_apply_pairs(A_ec, t_idx, nt, std_floor, k, S, st, ldt, out)
         return out[:, :nt]
+    fused = mask_ec is None and gather_apply_supported(nc, ne) and seg_plan(nc, k) is None
     mt, it, ldt = gather_stats(A_tc, mask_tc, e_idx, ne, std_floor, k)  # [test, enrol]
     if fused:
         gather_apply(A_ec, t_idx, nt, std_floor, k, S, mt, it, ldt, out)

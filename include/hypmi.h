@@ -267,7 +267,8 @@ int hypmi_scatter_block(const float* blk, int64_t ldb, const int32_t* ri, int64_
  * List layout (uint16, groups of eight so that one 16-byte load fetches eight entries of a list):
  *   entry j of the list of row q is idx[((j >> 3) * ldi + q) * 8 + (j & 7)],  ldi >= n_rows,
  * hypmi_topk_list_bytes(k, ldi) bytes in all, 16-byte aligned.
- * Cohorts up to ~40k entries are selected inside LDS; larger ones need the workspace.
+ * Every cohort the 16-bit lists can name is selected from registers (256 threads per row up to 24 576
+ * members, 512 above); `workspace` is not used and may be NULL (hypmi_topk_workspace_bytes returns 0).
  *
  * exact (optional): where the float64 value of an entry comes from.  Cohort members whose fp32 score
  * cannot be separated from a selection boundary (about 0.05 % of rows have one; the wrong member
@@ -284,7 +285,6 @@ int hypmi_scatter_block(const float* blk, int64_t ldb, const int32_t* ri, int64_
  *           makes the fp64 packed rows of just those rows and calls again with mode 2 and
  *           row_map = todo, n_rows = *todo_count: workgroup b re-selects row row_map[b] of A (and
  *           overwrites its list) with exact values and bounds from row b of G_rows / bnd_rows.
- *           Cohorts of up to 40 960 members.
  * counters (optional, device, 2 x uint64): rows with a re-decided boundary, rows skipped because more
  * than 64 entries tie with a boundary. */
 typedef struct {
@@ -313,11 +313,37 @@ int hypmi_topk_rows(const float* A, int64_t n_rows, int nc, int64_t lda, int k, 
  * X[n_rows x nc] and list q (layout above): mean[r,q] and istd[r,q] = 1 / max(std, std_floor) of
  * X[r, list_q] (population std).  With mask (uint8 [n_rows x nc], 0 = masked, X already zeroed
  * there) the moments are divided by the unmasked fraction as adapt_s_norm.py:54-60 does.
- * Rows of up to 40 880 cohort members (unmasked) are gathered from LDS, longer ones from global
- * memory, an order of magnitude slower. */
+ * Unmasked rows of up to 20 440 cohort members are gathered from LDS two (or four) at a time; up to
+ * 40 880 one at a time (callers that can partition the lists take hypmi_gather_stats_seg instead, which
+ * keeps two rows per workgroup); masked rows fit LDS up to 32 768 members; longer ones are gathered
+ * from global memory, an order of magnitude slower. */
 int hypmi_gather_stats(const float* X, int64_t n_rows, int nc, int64_t ldx, const unsigned char* mask,
                        int64_t ldm, const uint16_t* idx, int64_t ldi, int k, int64_t n_lists,
                        float std_floor, float* mean, float* istd, int64_t ldo, void* stream);
+
+/* Cohorts whose rows do not fit LDS two at a time (more than 20 440 members; the reference accepts any
+ * cohort, adapt_s_norm.py:30-44) without a mask: the cohort is cut into n_seg segments of seg_len members
+ * that do fit, the lists are partitioned by segment once (hypmi_segment_lists) and the statistics kernels
+ * walk every list once per segment with its moments carried in registers -- the same values as
+ * hypmi_gather_stats to fp32 rounding (the members of a list are added in another order).
+ * hypmi_gather_seg_plan returns 1 and the partition when this path applies to a cohort of nc members and
+ * lists of k (0: use hypmi_gather_stats / _pairs / _apply).  Segmented lists: `groups` groups of eight
+ * uint16 per list in the layout of hypmi_topk_rows (groups * ldi * 16 bytes, below 4 GiB), members as
+ * 1 + offset in their segment, every segment's part padded to whole groups with zeros; gstart holds
+ * (n_seg + 1) * ldi uint16, gstart[s * ldi + q] = first group of segment s of list q. */
+int hypmi_gather_seg_plan(int nc, int k, int* n_seg, int* seg_len, int* groups);
+int hypmi_segment_lists(const uint16_t* idx, int64_t ldi, int k, int64_t n_lists, int nc, uint16_t* seg_idx,
+                        uint16_t* gstart, void* stream);
+/* hypmi_gather_stats over segmented lists (idx: the lists before segmentation, walked for the rare
+ * selections that lie far from their row's bulk); istd == NULL: (mean, 1 / std) pairs in `mean`, ldo in pairs. */
+int hypmi_gather_stats_seg(const float* X, int64_t n_rows, int nc, int64_t ldx, const uint16_t* idx,
+                           const uint16_t* seg_idx, const uint16_t* gstart, int64_t ldi, int k, int64_t n_lists,
+                           float std_floor, float* mean, float* istd, int64_t ldo, void* stream);
+/* hypmi_gather_apply_pairs over segmented lists. */
+int hypmi_gather_apply_seg(const float* X, int64_t n_rows, int nc, int64_t ldx, const uint16_t* idx,
+                           const uint16_t* seg_idx, const uint16_t* gstart, int64_t ldi, int k, int64_t n_lists,
+                           float std_floor, const float* S, int64_t lds, const float* stats_t, int64_t ldt,
+                           float* out, int64_t ldo, void* stream);
 
 /* Diagnostic: the number of (row, list) pairs hypmi_gather_stats has recomputed around the list's
  * own first member since the last reset, because their selection lies so far from the row's mean

@@ -777,7 +777,8 @@ def test_pair_score_rows_of_very_different_size():
 @pytest.mark.parametrize("n,nc,k,disc,shift", [
     (7, 50, 10, 0, 0.0), (7, 50, 10, 0, -100.0), (5, 50, 10, 3, 0.0), (9, 700, 33, 0, 0.0),
     (4, 1500, 100, 5, 0.0), (6, 5000, 300, 0, 0.0), (3, 20000, 300, 0, 0.0), (3, 20000, 300, 7, -3.0),
-    (2, 40960, 1000, 0, 0.0), (3, 300, 300, 0, 0.0), (2, 45000, 64, 2, 1.0)])
+    (2, 40960, 1000, 0, 0.0), (3, 300, 300, 0, 0.0), (2, 45000, 64, 2, 1.0), (2, 53000, 300, 0, 0.0),
+    (3, 65536, 300, 3, -2.0)])
 def test_topk_rows_matches_stable_argsort(n, nc, k, disc, shift):
     """Every size class of the register-resident top-k (and the workspace path above 40 960) against a
     stable descending argsort: ranks discard .. discard+k-1, ties to the lower index (the order of
@@ -819,8 +820,9 @@ def test_topk_lists_are_ordered_by_bank_class():
 @pytest.mark.gpu
 @pytest.mark.parametrize("masked", [False, True])
 def test_adapt_s_norm_cohort_larger_than_lds(masked):
-    """45 000 cohort members: neither the register-resident top-k (40 960) nor an LDS-resident row
-    (40 960 fp32) applies; the workspace top-k and the global-memory gather give the same result."""
+    """45 000 cohort members: the register-resident top-k (40 960) does not apply, and the cohort does
+    not fit LDS two rows at a time; the workspace top-k with the segmented gather (unmasked) or the
+    global-memory gather (masked) give the same result."""
     from hyperion_amd.score_norm import AdaptSNorm
 
     rng = np.random.RandomState(17)
@@ -942,7 +944,11 @@ def test_prologue_pairs_equals_prologue_then_pair_rows(d, lda, K, n):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows,nc,k,lists", [
-    (5, 30_000, 300, 70),      # one row per workgroup (the row alone nearly fills LDS)
+    (5, 30_000, 300, 70),      # more than two rows' worth of LDS: the cohort is taken in two segments
+    (3, 50_000, 300, 1100),    # three segments, lists in a partial second round, odd row count
+    (4, 65_535, 64, 9000),     # the largest cohort (four segments), more lists than one workgroup takes
+    (2, 40_900, 7, 33),        # lists shorter than a group of eight over three segments
+    (1, 45_000, 300, 5),       # a single row
     (3, 20_440, 17, 1025),     # two rows per workgroup, the largest cohort that allows it; odd row count
     (2, 20_441, 8, 5),         # one member more: back to one row per workgroup
     (7, 9_000, 1, 33),         # four rows per workgroup, lists of one member
@@ -960,9 +966,14 @@ def test_gather_stats_shapes(rows, nc, k, lists):
     rng = np.random.RandomState(rows * 1000 + k)
     X = (rng.randn(rows, nc) * 4 - 9).astype(np.float32)
     X[0, :] += 50.0 * (rng.rand(nc) < 0.01)  # a few far outliers in one row
-    sel_src = (rng.randn(lists, nc) * 3).astype(np.float32)
-    idx = topk_rows(torch.from_numpy(sel_src).cuda(), k, 0)
+    if lists * nc <= 50_000_000:
+        sel_src = torch.from_numpy((rng.randn(lists, nc) * 3).astype(np.float32)).cuda()
+    else:  # what the lists are selected from only has to be random
+        sel_src = torch.randn((lists, nc), device="cuda", generator=torch.Generator(device="cuda").manual_seed(k)) * 3
+    idx = topk_rows(sel_src, k, 0)
+    del sel_src
     L = lists_to_numpy(idx, k)
+    assert np.all(np.sort(L, axis=1)[:, 1:] > np.sort(L, axis=1)[:, :-1]) and L.max() < nc  # k different members
     mean, istd, _ = gather_stats(torch.from_numpy(X).cuda(), None, idx, lists, 1e-5, k)
     mean, istd = mean[:, :lists].cpu().numpy().astype(np.float64), istd[:, :lists].cpu().numpy().astype(np.float64)
     sel = X.astype(np.float64)[:, L]  # [rows, lists, k]
@@ -973,7 +984,8 @@ def test_gather_stats_shapes(rows, nc, k, lists):
 
 
 @pytest.mark.gpu
-def test_gather_stats_tail_selection_and_constant_members():
+@pytest.mark.parametrize("nc", [20_000, 45_000])  # undivided, and in three segments
+def test_gather_stats_tail_selection_and_constant_members(nc):
     """Selections far out in the tail of their row (where a one-pass variance about the row's pivot
     would cancel) and selections of equal values: the kernel redoes those pairs around the list's own
     pivot; the count of such pairs is reported."""
@@ -985,7 +997,7 @@ def test_gather_stats_tail_selection_and_constant_members():
     from hyperion_amd.score_norm.adapt_s_norm import gather_stats, lists_to_numpy, topk_rows
 
     rng = np.random.RandomState(4)
-    rows, nc, k, lists = 6, 20_000, 300, 40
+    rows, k, lists = 6, 300, 40
     X = (rng.randn(rows, nc) * 6 - 14).astype(np.float32)
     X[2, :400] = 7.25          # a block of equal values
     X[3, :400] = 60.0 + 0.01 * rng.randn(400).astype(np.float32)  # a narrow cluster 12 sigma away
@@ -1012,15 +1024,18 @@ def test_gather_stats_tail_selection_and_constant_members():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("ne,nt,nc,k", [(37, 1500, 600, 50), (130, 70, 20_440, 300), (3, 2100, 30_000, 40),
-                                        (260, 1030, 4_000, 9), (6, 20_000, 600, 50)])  # last: lists split over blocks
+                                        (260, 1030, 4_000, 9), (6, 20_000, 600, 50),  # lists split over blocks
+                                        (131, 70, 45_000, 300), (5, 9_000, 65_535, 24)])  # cohorts taken in segments
 def test_gather_apply_equals_gather_then_apply(ne, nt, nc, k):
     """The Z-part statistics kernel that finishes the normalisation itself gives the bits of the two
     separate launches, for every rows-per-workgroup variant and ragged shapes (row groups are
-    renumbered in sets of 128, most of which are empty here)."""
+    renumbered in sets of 128, most of which are empty here); cohorts that are taken in segments have
+    the paired form only."""
     import torch
 
     from hyperion_amd import _lib, engine
-    from hyperion_amd.score_norm.adapt_s_norm import gather_apply, gather_apply_supported, gather_stats, topk_rows
+    from hyperion_amd.score_norm.adapt_s_norm import (gather_apply, gather_apply_supported, gather_pairs_supported,
+                                                      gather_stats, seg_plan, topk_rows)
 
     rng = np.random.RandomState(ne + nt)
     A_ec = torch.from_numpy((rng.randn(ne, nc) * 5 - 8).astype(np.float32)).cuda()
@@ -1036,11 +1051,13 @@ def test_gather_apply_equals_gather_then_apply(ne, nt, nc, k):
     _lib.check(lib.hypmi_asnorm_apply(engine._ptr(S), S.stride(0), ne, nt, engine._ptr(mz), engine._ptr(iz), ldz,
                                       engine._ptr(mt), engine._ptr(it), ldt, engine._ptr(ref), ld,
                                       engine.stream_ptr()))
-    assert gather_apply_supported(nc, ne)
-    out = torch.full((ne, ld), 7.0, dtype=torch.float32, device="cuda")
-    gather_apply(A_ec, t_idx, nt, 1e-5, k, S, mt, it, ldt, out)
-    assert torch.equal(out, ref)  # including the untouched padding columns
-    assert not gather_apply_supported(45_000, ne)
+    assert gather_pairs_supported(nc, ne, k)
+    if seg_plan(nc, k) is None:
+        assert gather_apply_supported(nc, ne)
+        out = torch.full((ne, ld), 7.0, dtype=torch.float32, device="cuda")
+        gather_apply(A_ec, t_idx, nt, 1e-5, k, S, mt, it, ldt, out)
+        assert torch.equal(out, ref)  # including the untouched padding columns
+    assert not gather_apply_supported(45_000, ne) and seg_plan(45_000, k) is not None and seg_plan(20_440, k) is None
     # the same two steps with mean and 1 / std of a (test, model) pair side by side in one array
     from hyperion_amd.score_norm.adapt_s_norm import gather_apply_pairs, gather_stats_pairs
 
