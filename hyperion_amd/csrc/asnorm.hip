@@ -1252,7 +1252,7 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
 // inside a segment is the one the selection kernel produced) and stored as 1 + (member - segment start);
 // every segment's part is padded to whole groups with entries 0, which is the LDS entry that holds zeros.
 // gstart[s ldi + q] (s = 0 .. S) is the first group of segment s of list q.
-constexpr int SG_NL = 8;        // lists per lane of one workgroup (their moments: 4 R registers each)
+constexpr int SG_NL = 12;        // lists per lane of one workgroup (their moments: 4 R registers each)
 constexpr int SG_MAX_SEG = 8;
 
 __global__ __launch_bounds__(256) void segment_lists_kernel(const uint16_t* __restrict__ idx8, int64_t ldi, int k,
@@ -1462,6 +1462,7 @@ __global__ __launch_bounds__(GS_THREADS) void gather_seg_kernel(
             }
 #undef HYPMI_SEG_GROUP
 #undef HYPMI_SEG_LOAD
+            rotate_priority((wave >> 2) + l + 1);
             // the next list's moments move to the front
 #pragma unroll
             for (int rr = 0; rr < R; ++rr) {
@@ -1481,58 +1482,77 @@ __global__ __launch_bounds__(GS_THREADS) void gather_seg_kernel(
     // after S x SG_NL rotations the moments of list l are back in place l
     const float inv_k = 1.0f / (float)k, floor2 = floor_ * floor_, inv_floor = 1.0f / floor_;
     const uint4* base = reinterpret_cast<const uint4*>(idx8);
+    // The lists are finished in batches: what a batch needs from memory (APPLY: raw scores and the other
+    // side's statistics) is requested for all its lists before the first is used -- one round trip per
+    // batch, not one per list.
+    constexpr int LB = SG_NL % 4 == 0 ? 4 : (SG_NL % 3 == 0 ? 3 : 1);
 #pragma unroll
-    for (int l = 0; l < SG_NL; ++l) {
-        const int64_t q = q0 + (int64_t)l * GS_THREADS + tid;
-        if (l >= nl || q >= q1) continue;
-        float lp[R], m1[R], m2[R];
-        bool redo = false;
+    for (int l0 = 0; l0 < SG_NL; l0 += LB) {
+        typename LdsVec<2 * R>::type pmi[LB];
+        typename LdsVec<R>::type pm[LB], pi[LB];
+        float sc[LB][R];
+        if (APPLY) {
 #pragma unroll
-        for (int rr = 0; rr < R; ++rr) {
-            lp[rr] = rowpiv[rr];
-            m1[rr] = s1[l][rr];
-            m2[rr] = s2[l][rr];
-            const float md = m1[rr] * inv_k, ms = m2[rr] * inv_k;
-            redo |= fmaf(-md, md, ms) * GP_AMP < ms;  // false for NaN: those stay NaN
+            for (int u = 0; u < LB; ++u) {
+                int64_t q = q0 + (int64_t)(l0 + u) * GS_THREADS + tid;
+                q = q < q1 ? q : q1 - 1;
+                if (PAIRS) {
+                    pmi[u] = load_pairs<R>(ap.mt + (q * ap.ldt + r0) * 2);
+                } else {
+                    pm[u] = *reinterpret_cast<const typename LdsVec<R>::type*>(ap.mt + q * ap.ldt + r0);
+                    pi[u] = *reinterpret_cast<const typename LdsVec<R>::type*>(ap.it + q * ap.ldt + r0);
+                }
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                    const int64_t e = r0 + rr < n_rows ? r0 + rr : n_rows - 1;
+                    sc[u][rr] = __builtin_nontemporal_load(ap.S + e * ap.lds + q);
+                }
+            }
         }
-        if (redo) {  // a selection far from the row pivot: again around the list's own first member
-            const ShiftedMoments<R> m = list_moments_shifted<R>(X, ldx, r0, n_rows, base + q, ldi, k);
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            const int l = l0 + u;
+            const int64_t q = q0 + (int64_t)l * GS_THREADS + tid;
+            if (l >= nl || q >= q1) continue;
+            float lp[R], m1[R], m2[R];
+            bool redo = false;
 #pragma unroll
             for (int rr = 0; rr < R; ++rr) {
-                lp[rr] = m.piv[rr];
-                m1[rr] = m.s1[rr];
-                m2[rr] = m.s2[rr];
+                lp[rr] = rowpiv[rr];
+                m1[rr] = s1[l][rr];
+                m2[rr] = s2[l][rr];
+                const float md = m1[rr] * inv_k, ms = m2[rr] * inv_k;
+                redo |= fmaf(-md, md, ms) * GP_AMP < ms;  // false for NaN: those stay NaN
             }
-            atomicAdd(&g_gather_redo, 1ull);
-        }
-        typename LdsVec<2 * R>::type pmi;
-        typename LdsVec<R>::type pm, pi;
-        if (PAIRS) {
-            pmi = load_pairs<R>(ap.mt + (q * ap.ldt + r0) * 2);
-        } else if (APPLY) {
-            pm = *reinterpret_cast<const typename LdsVec<R>::type*>(ap.mt + q * ap.ldt + r0);
-            pi = *reinterpret_cast<const typename LdsVec<R>::type*>(ap.it + q * ap.ldt + r0);
-        }
+            if (redo) {  // a selection far from the row pivot: again around the list's own first member
+                const ShiftedMoments<R> m = list_moments_shifted<R>(X, ldx, r0, n_rows, base + q, ldi, k);
 #pragma unroll
-        for (int rr = 0; rr < R; ++rr) {
-            if (r0 + rr >= n_rows) continue;
-            const float md = m1[rr] * inv_k;
-            float var = fmaf(-md, md, m2[rr] * inv_k);
-            var = var > 0.f ? var : (var == var ? 0.f : var);  // NaN stays NaN
-            const float is = var < floor2 ? inv_floor : __builtin_amdgcn_rsqf(var);
-            const float m = fmaf(m1[rr], inv_k, lp[rr]);
-            if (PAIRS) {
-                const float sc = __builtin_nontemporal_load(ap.S + (r0 + rr) * ap.lds + q);
-                ap.out[(r0 + rr) * ap.ldo + q] = asnorm_value(sc, m, is, pmi[2 * rr], pmi[2 * rr + 1]);
-            } else if (APPLY) {
-                const float sc = __builtin_nontemporal_load(ap.S + (r0 + rr) * ap.lds + q);
-                ap.out[(r0 + rr) * ap.ldo + q] =
-                    asnorm_value(sc, m, is, lds_vec_elem<R>(pm, rr), lds_vec_elem<R>(pi, rr));
-            } else if (istd == nullptr) {
-                reinterpret_cast<float2*>(mean)[(r0 + rr) * ldo + q] = make_float2(m, is);
-            } else {
-                mean[(r0 + rr) * ldo + q] = m;
-                istd[(r0 + rr) * ldo + q] = is;
+                for (int rr = 0; rr < R; ++rr) {
+                    lp[rr] = m.piv[rr];
+                    m1[rr] = m.s1[rr];
+                    m2[rr] = m.s2[rr];
+                }
+                atomicAdd(&g_gather_redo, 1ull);
+            }
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                if (r0 + rr >= n_rows) continue;
+                const float md = m1[rr] * inv_k;
+                float var = fmaf(-md, md, m2[rr] * inv_k);
+                var = var > 0.f ? var : (var == var ? 0.f : var);  // NaN stays NaN
+                const float is = var < floor2 ? inv_floor : __builtin_amdgcn_rsqf(var);
+                const float m = fmaf(m1[rr], inv_k, lp[rr]);
+                if (PAIRS) {
+                    ap.out[(r0 + rr) * ap.ldo + q] = asnorm_value(sc[u][rr], m, is, pmi[u][2 * rr], pmi[u][2 * rr + 1]);
+                } else if (APPLY) {
+                    ap.out[(r0 + rr) * ap.ldo + q] = asnorm_value(sc[u][rr], m, is, lds_vec_elem<R>(pm[u], rr),
+                                                                  lds_vec_elem<R>(pi[u], rr));
+                } else if (istd == nullptr) {
+                    reinterpret_cast<float2*>(mean)[(r0 + rr) * ldo + q] = make_float2(m, is);
+                } else {
+                    mean[(r0 + rr) * ldo + q] = m;
+                    istd[(r0 + rr) * ldo + q] = is;
+                }
             }
         }
     }
