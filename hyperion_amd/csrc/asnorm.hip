@@ -19,6 +19,8 @@
 // Index lists are uint16 (cohort < 65536) in groups of eight: entry j of list q lives at
 // idx8[((j >> 3) * ldi + q) * 8 + (j & 7)], so a lane fetches eight consecutive entries of its list
 // with one 16-byte load and a wave's loads are contiguous (1 KiB).
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -932,7 +934,7 @@ template <int R, int MODE>
 __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
     const float* __restrict__ X, int64_t ldx, int64_t n_rows, int nc, const uint16_t* __restrict__ idx8,
     int64_t ldi, int k, int64_t Q, int64_t q_per_block, float floor_, float* __restrict__ mean,
-    float* __restrict__ istd, int64_t ldo, ApplyArgs ap) {
+    float* __restrict__ istd, int64_t ldo, ApplyArgs ap, unsigned* __restrict__ front) {
     constexpr bool APPLY = MODE != 0, PAIRS = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) float xr[];
     float* red = xr + (size_t)nc * R;
@@ -1045,7 +1047,18 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
     // lists); with a fixed share each the first wave of a workgroup finished well before the last, and a SIMD
     // with one or two waves left cannot fill its issue slots.
     unsigned* unit_counter = reinterpret_cast<unsigned*>(xr + (size_t)nc * R + 8);
-    if (tid == 0) *unit_counter = 2 * (GS_THREADS / 64);
+    // Where the workgroup starts in its block of lists.  Every row group walks the same lists, and a list
+    // block is larger than an L2; workgroups that started at different times would stream different parts
+    // of it through the L2 of their XCD at once.  `front` (one counter per XCD class of workgroups and list
+    // block, zero at launch) holds the furthest position any of them has reached, in units, counted without
+    // wrapping: a new workgroup starts there and wraps around, so that the workgroups of an XCD read the same
+    // few rounds of lists (and, with APPLY, the same lines of the other side's statistics) at the same time.
+    unsigned* my_front = front ? front + (blockIdx.y * 8 + (blockIdx.x & 7)) : nullptr;
+    unsigned* start_word = reinterpret_cast<unsigned*>(xr + (size_t)nc * R + 9);
+    if (tid == 0) {
+        *unit_counter = 2 * (GS_THREADS / 64);
+        *start_word = my_front ? __hip_atomic_load(my_front, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    }
     __syncthreads();
     unsigned keep[4], fill[4];
 #pragma unroll
@@ -1058,6 +1071,10 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
     const int U = __builtin_amdgcn_readfirstlane((int)((q1 - q0 + 63) >> 6));  // units of the block
     const int uw = __builtin_amdgcn_readfirstlane(wave);
     if (uw >= U) return;  // (no barrier follows)
+    const unsigned v_start = __builtin_amdgcn_readfirstlane(*start_word);
+    const int u0 = (int)(v_start % (unsigned)U);
+    // unit number (the order in which this workgroup takes them) -> position in the block
+    auto place = [&](int u) -> int { return u + u0 < U ? u + u0 : u + u0 - U; };
     // A unit is claimed one unit ahead of the index stream, which itself runs GP_RING groups ahead of the
     // arithmetic; with lists of at most GP_RING groups the stream could cross two units before the
     // arithmetic has left one, and the shares stay fixed (unit u is followed by u + 16).
@@ -1074,8 +1091,9 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
     const unsigned voff = (unsigned)lane * 16u;
     int u_ld = uw, u_next = uw + WAVES, g_ld = 0;  // uniform: unit and group of the next load, the unit after it
     unsigned claim = 0;                            // lane 0: the unit claimed at the last crossing
-    const char* sp = sp0 + (int64_t)u_ld * 1024;
-    unsigned nrec = (unsigned)((q1 - q0 - 64 * (int64_t)u_ld < 64 ? q1 - q0 - 64 * (int64_t)u_ld : 64) * 16);
+    const char* sp = sp0 + (int64_t)place(u_ld) * 1024;
+    unsigned nrec =
+        (unsigned)((q1 - q0 - 64 * (int64_t)place(u_ld) < 64 ? q1 - q0 - 64 * (int64_t)place(u_ld) : 64) * 16);
     int u_after = u_next;  // the unit the arithmetic takes after its current one
 #define HYPMI_NEXT_LOAD(dst)                                                                              \
     {                                                                                                     \
@@ -1096,9 +1114,14 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
                 u_next = u_ld + WAVES;                                                                    \
             }                                                                                             \
             if (u_ld < U) {                                                                               \
-                const int64_t left = q1 - q0 - 64 * (int64_t)u_ld;                                        \
-                sp = sp0 + (int64_t)u_ld * 1024;                                                          \
+                const int at_ = place(u_ld);                                                              \
+                const int64_t left = q1 - q0 - 64 * (int64_t)at_;                                         \
+                sp = sp0 + (int64_t)at_ * 1024;                                                           \
                 nrec = (unsigned)((left < 64 ? left : 64) * 16);                                          \
+                /* one wave per workgroup reports how far the workgroup has come */                      \
+                if (my_front && uw == 0 && lane == 0)                                                     \
+                    __hip_atomic_fetch_max(my_front, v_start + (unsigned)u_ld, __ATOMIC_RELAXED,          \
+                                           __HIP_MEMORY_SCOPE_AGENT);                                     \
             } else {                                                                                      \
                 sp -= (int64_t)(G - 1) * step_b; /* the stream is over: further loads re-read a unit */   \
             }                                                                                             \
@@ -1118,7 +1141,7 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
     float ps[R];
 #define HYPMI_APPLY_PREFETCH(UNIT)                                                                  \
     if (APPLY) {                                                                                    \
-        int64_t qq = q0 + lane + (int64_t)(UNIT) * 64;                                              \
+        int64_t qq = q0 + lane + (int64_t)place(UNIT) * 64;                                         \
         qq = qq < q1 ? qq : q1 - 1;                                                                 \
         if (PAIRS) {                                                                                \
             pmi = load_pairs<R>(ap.mt + (qq * ap.ldt + r0) * 2);                                    \
@@ -1175,7 +1198,7 @@ __global__ __launch_bounds__(GS_THREADS) void gather_pivot_kernel(
                 moment_step(s1[rr], s2[rr], lds_vec_elem<R>(val[e], rr));                                       \
         if (++g == G) {                                                                                         \
             /* The sums carry fp32 rounding (about 1e-6 relative); so does this arithmetic. */                  \
-            const int64_t q = q0 + lane + (int64_t)u_cp * 64;                                                   \
+            const int64_t q = q0 + lane + (int64_t)place(u_cp) * 64;                                            \
             const bool live_q = q < q1;                                                                         \
             float lp[R]; /* what the moments are taken around: the row pivot, or after a redo the list's own */ \
             bool redo = false;                                                                                  \
@@ -1805,6 +1828,40 @@ inline int64_t pivot_lds_bytes(int nc, int R) {
     return round_up(((int64_t)nc * R + GP_SCRATCH_FLOATS) * 4, 16);
 }
 
+}  // namespace
+// The `front` counters of the gather launches (see gather_pivot_kernel): a pool of sets, one set per launch
+// in turn (launches that overlap on different streams must not share a set; FRONT_SETS launches apart they may).
+constexpr int FRONT_SETS = 32, FRONT_BLOCKS = 16;
+static __device__ unsigned g_gather_front[FRONT_SETS * FRONT_BLOCKS * 8];
+namespace {
+std::mutex front_mutex;
+unsigned* front_base[64];  // per device
+unsigned front_seq = 0;
+
+// zeroed counters for a launch with `blocks` list blocks on the current device (nullptr: none, the launch
+// has more list blocks than a set covers -- its workgroups all start at the first list)
+int next_front_set(int64_t blocks, hipStream_t stream, unsigned** set) {
+    *set = nullptr;
+    if (blocks > FRONT_BLOCKS) return HYPMI_OK;
+    int dev = -1;
+    HYPMI_HIP(hipGetDevice(&dev));
+    HYPMI_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+    unsigned* at;
+    {
+        std::lock_guard<std::mutex> lock(front_mutex);
+        if (!front_base[dev]) {
+            void* ptr = nullptr;
+            HYPMI_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_gather_front)));
+            HYPMI_REQUIRE(ptr != nullptr, "no device address for the gather front counters");
+            front_base[dev] = static_cast<unsigned*>(ptr);
+        }
+        at = front_base[dev] + (size_t)(front_seq++ % FRONT_SETS) * FRONT_BLOCKS * 8;
+    }
+    HYPMI_HIP(hipMemsetAsync(at, 0, (size_t)blocks * 8 * sizeof(unsigned), stream));
+    *set = at;
+    return HYPMI_OK;
+}
+
 template <int R, int MODE = 0>
 int launch_gather_pivot(const float* X, int64_t n_rows, int nc, int64_t ldx, const uint16_t* idx8, int64_t ldi,
                         int k, int64_t n_lists, float std_floor, float* mean, float* istd, int64_t ldo,
@@ -1820,9 +1877,14 @@ int launch_gather_pivot(const float* X, int64_t n_rows, int nc, int64_t ldx, con
     const int64_t gx = MODE != 0 ? round_up(groups, 8 * GP_XCD_GROUPS) : groups;
     HYPMI_REQUIRE(gx <= 0x7fffffffLL, "gather_stats: too many rows");
     HYPMI_REQUIRE((q_per_block / GS_THREADS) * ((k + 7) / 8) < 0x7fffffffLL, "gather_stats: lists too long");
+    unsigned* front = nullptr;
+    if (q_per_block >= 4 * GS_THREADS) {  // (short blocks stay in L2 whatever the order)
+        const int rc = next_front_set(chunks, stream, &front);
+        if (rc != HYPMI_OK) return rc;
+    }
     hipLaunchKernelGGL((gather_pivot_kernel<R, MODE>), dim3((unsigned)gx, (unsigned)chunks), dim3(GS_THREADS),
                        lds_need, stream, X, ldx, n_rows, nc, idx8, ldi, k, n_lists, q_per_block, std_floor, mean,
-                       istd, ldo, ap);
+                       istd, ldo, ap, front);
     HYPMI_HIP(hipGetLastError());
     return HYPMI_OK;
 }
