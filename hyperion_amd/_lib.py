@@ -150,6 +150,10 @@ SIGNATURES = {
     "hypmi_gather_redo_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
     "hypmi_asnorm_apply": (ctypes.c_int, [c_void_p, i64, i64, i64, c_void_p, c_void_p, i64, c_void_p,
                                           c_void_p, i64, c_void_p, i64, c_void_p]),
+    "hypmi_asnorm_refine": (ctypes.c_int, [c_void_p, i64, c_void_p, i64, c_void_p, i64, i64, i64, ctypes.c_int,
+                                           c_void_p, i64, c_void_p, i64, ctypes.c_int, c_void_p, c_void_p, i64,
+                                           c_void_p, c_void_p, i64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                           c_void_p, i64, c_void_p, c_void_p]),
     "hypmi_mask_zero": (ctypes.c_int, [c_void_p, i64, i64, i64, c_void_p, i64, c_void_p]),
     "hypmi_transpose": (ctypes.c_int, [c_void_p, i64, i64, i64, c_void_p, i64, c_void_p]),
     "hypmi_row_meanstd": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, i64, c_void_p, i64,

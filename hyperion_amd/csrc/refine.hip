@@ -214,6 +214,71 @@ __global__ __launch_bounds__(256) void refine_scores_kernel(float* __restrict__ 
     if (counter && tid == 0 && total) atomicAdd(counter, (unsigned long long)total);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Refinement of adaptively normalised scores.  A normalised score is a difference of numbers of
+// magnitude (|x| + |mean|) / std that cancel to about 0 for most non-target trials, so its fp32 value
+// cannot hold a relative tolerance near zero.  A wave looks at 64 consecutive tests of one enrolment row:
+// an entry whose fp32 error estimate
+//     coeff * [ (|x| + |mz|) iz + (|x| + |mt|) it + 8 + 16 (|z| + |t|) ]
+// (x raw score, (mz, iz) / (mt, it) the fp32 cohort statistics of the two parts, z / t the two
+// normalised terms: rounding of the inputs and of the means, about four standard deviations of
+// accumulation error, and the up to four bits the one-pass variance may lose) exceeds rel_tol * |s| is
+// recomputed by the whole wave from the float64 matrices over the same cohort selections, with the
+// two-pass mean and deviation of hyperion/score_norm/adapt_s_norm.py:58-63,81-88.
+__global__ __launch_bounds__(256) void asnorm_refine_kernel(
+    const double* __restrict__ S64, int64_t lds64, const double* __restrict__ E64, int64_t lde,
+    const double* __restrict__ T64, int64_t ldt64, int64_t ne, int64_t nt, const uint16_t* __restrict__ t_idx,
+    int64_t ldti, const uint16_t* __restrict__ e_idx, int64_t ldei, int k, const float* __restrict__ mz,
+    const float* __restrict__ iz, int64_t ldz, const float* __restrict__ mt, const float* __restrict__ it,
+    int64_t ldt, float rel_tol, float coeff, double std_floor, float* __restrict__ out, int64_t ldo,
+    unsigned long long* __restrict__ counter) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t e = blockIdx.y, t0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    if (e >= ne || t0 >= nt) return;
+    const int64_t t = t0 + lane;
+    bool flag = false;
+    if (t < nt) {
+        const float x = (float)S64[e * lds64 + t];
+        const float m_z = mz[e * ldz + t], i_z = iz[e * ldz + t], m_t = mt[t * ldt + e], i_t = it[t * ldt + e];
+        const float z = (x - m_z) * i_z, tn = (x - m_t) * i_t;
+        const float bound = coeff * ((fabsf(x) + fabsf(m_z)) * i_z + (fabsf(x) + fabsf(m_t)) * i_t + 8.f +
+                                     16.f * (fabsf(z) + fabsf(tn)));
+        flag = !(rel_tol * fabsf(out[e * ldo + t]) >= bound);  // also catches NaN
+    }
+    unsigned long long todo = __ballot(flag);
+    if (!todo) return;
+    const unsigned n_todo = (unsigned)__popcll(todo);
+    const double* erow = E64 + e * lde;
+    const double inv_k = 1.0 / (double)k;
+    while (todo) {
+        const int64_t tt = t0 + __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const double* trow = T64 + tt * ldt64;
+        double sz = 0.0, st = 0.0;
+        for (int j = lane; j < k; j += 64) {
+            const int64_t g = (int64_t)(j >> 3) * 8, u = j & 7;
+            sz += erow[t_idx[g * ldti + tt * 8 + u]];
+            st += trow[e_idx[g * ldei + e * 8 + u]];
+        }
+        const double mean_z = wave_sum(sz) * inv_k, mean_t = wave_sum(st) * inv_k;
+        double vz = 0.0, vt = 0.0;
+        for (int j = lane; j < k; j += 64) {
+            const int64_t g = (int64_t)(j >> 3) * 8, u = j & 7;
+            const double dz = erow[t_idx[g * ldti + tt * 8 + u]] - mean_z;
+            const double dt = trow[e_idx[g * ldei + e * 8 + u]] - mean_t;
+            vz = fma(dz, dz, vz);
+            vt = fma(dt, dt, vt);
+        }
+        const double sd_z = fmax(sqrt(wave_sum(vz) * inv_k), std_floor);
+        const double sd_t = fmax(sqrt(wave_sum(vt) * inv_k), std_floor);
+        if (lane == 0) {
+            const double x = S64[e * lds64 + tt];
+            out[e * ldo + tt] = (float)(((x - mean_z) / sd_z + (x - mean_t) / sd_t) / sqrt(2.0));
+        }
+    }
+    if (counter && lane == 0) atomicAdd(counter, (unsigned long long)n_todo);
+}
+
 }  // namespace
 
 extern "C" int hypmi_gemm_nt_f64(const double* A, int64_t m, int64_t lda, const double* B, int64_t n,
@@ -303,6 +368,32 @@ extern "C" int hypmi_refine_scores(float* S, int64_t lds_, int64_t n1, int64_t n
         hipLaunchKernelGGL(refine_scores_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0,
                            static_cast<hipStream_t>(stream_), S + row0 * lds_, lds_, n1 - row0, n2,
                            G1 + row0 * ldg, G2, ldg, K, bnd1 + 2 * row0, bnd2, rel_tol, err_coeff, counter);
+    }
+    HYPMI_HIP(hipGetLastError());
+    return HYPMI_OK;
+}
+
+extern "C" int hypmi_asnorm_refine(const double* S64, int64_t lds64, const double* E64, int64_t lde,
+                                   const double* T64, int64_t ldt64, int64_t ne, int64_t nt, int nc,
+                                   const uint16_t* t_idx, int64_t ldti, const uint16_t* e_idx, int64_t ldei, int k,
+                                   const float* mz, const float* iz, int64_t ldz, const float* mt, const float* it,
+                                   int64_t ldt, float rel_tol, float err_coeff, float std_floor, float* out,
+                                   int64_t ldo, unsigned long long* counter, void* stream_) {
+    HYPMI_REQUIRE(S64 && E64 && T64 && t_idx && e_idx && mz && iz && mt && it && out, "asnorm_refine: null pointer");
+    HYPMI_REQUIRE(ne >= 0 && nt >= 0 && nc > 0 && k > 0 && k <= nc, "asnorm_refine: bad shape");
+    HYPMI_REQUIRE(lds64 >= nt && lde >= nc && ldt64 >= nc && ldz >= nt && ldt >= ne && ldo >= nt && ldti >= nt &&
+                      ldei >= ne,
+                  "asnorm_refine: leading dimension too small");
+    HYPMI_REQUIRE(rel_tol > 0.f && err_coeff > 0.f, "asnorm_refine: tolerances must be positive");
+    if (ne == 0 || nt == 0) return HYPMI_OK;
+    const int64_t gx = (nt + 255) / 256;
+    HYPMI_REQUIRE(gx <= 0x7fffffff, "asnorm_refine: too many tests per call");
+    for (int64_t e0 = 0; e0 < ne; e0 += 65535) {
+        const int64_t rows = ne - e0 < 65535 ? ne - e0 : 65535;
+        hipLaunchKernelGGL(asnorm_refine_kernel, dim3((unsigned)gx, (unsigned)rows), dim3(256), 0,
+                           static_cast<hipStream_t>(stream_), S64 + e0 * lds64, lds64, E64 + e0 * lde, lde, T64, ldt64,
+                           rows, nt, t_idx, ldti, e_idx + e0 * 8, ldei, k, mz + e0 * ldz, iz + e0 * ldz, ldz, mt + e0,
+                           it + e0, ldt, rel_tol, err_coeff, (double)std_floor, out + e0 * ldo, ldo, counter);
     }
     HYPMI_HIP(hipGetLastError());
     return HYPMI_OK;

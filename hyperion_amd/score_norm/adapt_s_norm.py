@@ -245,11 +245,21 @@ def gather_apply(X, idx, n_lists, std_floor, k, S, mt, it, ldt, out):
     return out
 
 
+# fp32 error estimate of a normalised score, in units of 2^-24 times the magnitudes that enter it (see
+# hypmi_asnorm_refine): the largest error seen over the parity problems is a fifth of the estimate.
+REFINE_ERR_COEFF = 2.0 ** -24
+
+
 def adapt_s_norm_device(S, A_ec, A_tc, nbest, nbest_discard, mask_ec=None, mask_tc=None,
-                        std_floor=1e-5, exact_ec=None, exact_tc=None):
+                        std_floor=1e-5, exact_ec=None, exact_tc=None, refine=None):
     """Adaptive S-norm on device matrices: S [enrol, test], A_ec [enrol, cohort], A_tc [test, cohort]
     (already zeroed where masked).  exact_ec / exact_tc: see topk_rows.  Returns a device
-    [enrol, test] tensor."""
+    [enrol, test] tensor.
+
+    refine (unmasked only): {"S64", "E64", "T64"} = the float64 device matrices the three fp32 ones were
+    rounded from, optional "rel_tol" (0.5e-4) and "err_coeff": entries whose fp32 error estimate exceeds
+    rel_tol * |score| are recomputed from them over the same selections (hypmi_asnorm_refine); the dict
+    receives "refined" = their number."""
     torch = engine.require_gpu()
     lib = _lib.load()
     ne, nt = S.shape
@@ -263,6 +273,25 @@ def adapt_s_norm_device(S, A_ec, A_tc, nbest, nbest_discard, mask_ec=None, mask_
         return out[:, :nt]
     t_idx = topk_rows(A_tc, k, int(nbest_discard), exact_tc)  # per test: cohort ranked by coh-vs-test
     e_idx = topk_rows(A_ec, k, int(nbest_discard), exact_ec)  # per enrol: cohort ranked by enr-vs-coh
+    if refine is not None:
+        assert mask_ec is None and mask_tc is None, "refinement of masked scores is not available"
+        S64, E64, T64 = refine["S64"], refine["E64"], refine["T64"]
+        for a, b in ((S64, S), (E64, A_ec), (T64, A_tc)):
+            assert a.dtype == torch.float64 and tuple(a.shape) == tuple(b.shape) and a.stride(1) == 1
+        mt, it, ldt = gather_stats(A_tc, None, e_idx, ne, std_floor, k)  # [test, enrol]
+        mz, iz, ldz = gather_stats(A_ec, None, t_idx, nt, std_floor, k)  # [enrol, test]
+        _lib.check(lib.hypmi_asnorm_apply(engine._ptr(S), S.stride(0), ne, nt, engine._ptr(mz), engine._ptr(iz), ldz,
+                                          engine._ptr(mt), engine._ptr(it), ldt, engine._ptr(out), ld,
+                                          engine.stream_ptr()))
+        counter = torch.zeros(1, dtype=torch.int64, device=S.device)
+        _lib.check(lib.hypmi_asnorm_refine(
+            engine._ptr(S64), S64.stride(0), engine._ptr(E64), E64.stride(0), engine._ptr(T64), T64.stride(0), ne, nt,
+            nc, engine._ptr(t_idx), t_idx.stride(0) // 8, engine._ptr(e_idx), e_idx.stride(0) // 8, k, engine._ptr(mz),
+            engine._ptr(iz), ldz, engine._ptr(mt), engine._ptr(it), ldt, float(refine.get("rel_tol", 0.5e-4)),
+            float(refine.get("err_coeff", REFINE_ERR_COEFF)), float(std_floor), engine._ptr(out), ld,
+            engine._ptr(counter), engine.stream_ptr()))
+        refine["refined"] = int(counter.item())
+        return out[:, :nt]
     if mask_ec is None and mask_tc is None and gather_pairs_supported(nc, min(ne, nt), k):
         # T-part mean and 1 / std side by side: one line per list in the Z part
         st, ldt = gather_stats_pairs(A_tc, e_idx, ne, std_floor, k)  # [test, enrol, 2]
@@ -286,16 +315,23 @@ class AdaptSNorm(ScoreNorm):
     dropping the `nbest_discard` closest.  The std floor is the reference's literal 1e-5 (its
     `std_floor` attribute is not consulted there either).  Caller arrays are never modified;
     a tie exactly at the selection boundary goes to the lower cohort index (numpy's argsort leaves
-    it unspecified)."""
+    it unspecified).
 
-    def __init__(self, nbest=100, nbest_discard=0, **kwargs):
+    refine: the reference works in float64; the device normalises in fp32, which leaves a normalised
+    score near zero (most non-target trials) with an absolute error of a few 1e-6 and no relative accuracy.
+    With refine=True such entries are recomputed from the float64 inputs on the device, so that every score
+    is within 1e-4 RELATIVE of the reference's; None (default) = whenever the three score matrices arrive as
+    float64 host arrays without masks.  `last_refined` holds the number of entries recomputed."""
+
+    def __init__(self, nbest=100, nbest_discard=0, refine=None, **kwargs):
         super().__init__(**kwargs)
         self.nbest = nbest
         self.nbest_discard = nbest_discard
+        self.refine = refine
+        self.last_refined = None
 
     def predict(self, scores, scores_coh_test, scores_enr_coh, mask_coh_test=None, mask_enr_coh=None):
         torch = engine.require_gpu()
-        S = dev_matrix(scores)
         host_ec = not isinstance(scores_enr_coh, torch.Tensor)
         host_ct = not isinstance(scores_coh_test, torch.Tensor)
         wide = lambda a: np.asarray(a).dtype.itemsize > 4  # noqa: E731  (fp32 arrays lose nothing on the device)
@@ -304,6 +340,18 @@ class AdaptSNorm(ScoreNorm):
         # to the device once, as float64, and are narrowed there.
         exact_ec = exact_tc = None
         m_ec = m_tc = None
+        all64 = (mask_enr_coh is None and mask_coh_test is None and host_ec and host_ct
+                 and not isinstance(scores, torch.Tensor) and wide(scores) and wide(scores_enr_coh)
+                 and wide(scores_coh_test))
+        refine = all64 if self.refine is None else bool(self.refine)
+        if refine and not all64:
+            raise ValueError("AdaptSNorm(refine=True) needs the three score matrices as float64 host arrays, unmasked")
+        self.last_refined = None
+        if refine:
+            S64 = engine.upload64(scores)
+            S = engine.upload(S64)
+        else:
+            S = dev_matrix(scores)
         if mask_enr_coh is None and host_ec and wide(scores_enr_coh):
             E64 = engine.upload64(scores_enr_coh)
             EC = engine.upload(E64)
@@ -330,8 +378,11 @@ class AdaptSNorm(ScoreNorm):
             m_ec = dev_mask(mask_enr_coh, EC.shape)
             EC = EC.clone() if not host_ec else EC
             zero_masked(EC, m_ec)
+        ref = {"S64": S64, "E64": E64, "T64": T64} if refine else None
         out = adapt_s_norm_device(S, EC, TC, self.nbest, self.nbest_discard, m_ec, m_tc,
-                                  exact_ec=exact_ec, exact_tc=exact_tc)
+                                  exact_ec=exact_ec, exact_tc=exact_tc, refine=ref)
+        if ref is not None:
+            self.last_refined = ref["refined"]
         skipped = sum(e["counters"][1] for e in (exact_ec, exact_tc) if e is not None and "counters" in e)
         if skipped:
             import warnings

@@ -356,6 +356,21 @@ int hypmi_asnorm_apply(const float* S, int64_t lds, int64_t ne, int64_t nt, cons
                        const float* iz, int64_t ldz, const float* mt, const float* it, int64_t ldt,
                        float* out, int64_t ldo, void* stream);
 
+/* Float64 refinement of adaptively normalised scores: the reference computes adapt_s_norm.py:46-88 in
+ * float64 throughout, and a normalised score is a difference that cancels to about zero for most
+ * non-target trials, where no fp32 evaluation holds a relative tolerance.  out [ne x nt] (fp32, from
+ * hypmi_asnorm_apply over the statistics mz / iz [ne x nt] and mt / it [nt x ne]) is scanned; an entry
+ * whose fp32 error estimate err_coeff * ((|x| + |mz|) iz + (|x| + |mt|) it + 8 + 16 (|z| + |t|)) exceeds
+ * rel_tol * |out| is recomputed from the float64 matrices S64 [ne x nt], E64 [ne x nc] (enrol-vs-cohort)
+ * and T64 [nt x nc] (test-vs-cohort) over the same selections t_idx / e_idx (layout of hypmi_topk_rows),
+ * two-pass mean and deviation, deviation clipped at std_floor, and stored rounded to fp32.  counter
+ * (device, may be NULL) is incremented by the number of entries recomputed.  Unmasked scores only. */
+int hypmi_asnorm_refine(const double* S64, int64_t lds64, const double* E64, int64_t lde, const double* T64,
+                        int64_t ldt64, int64_t ne, int64_t nt, int nc, const uint16_t* t_idx, int64_t ldti,
+                        const uint16_t* e_idx, int64_t ldei, int k, const float* mz, const float* iz, int64_t ldz,
+                        const float* mt, const float* it, int64_t ldt, float rel_tol, float err_coeff,
+                        float std_floor, float* out, int64_t ldo, unsigned long long* counter, void* stream);
+
 /* hypmi_gather_stats (without mask) and hypmi_asnorm_apply in one launch (adapt_s_norm.py:46-63 and
  * 88): X = enrol-vs-cohort scores [n_rows x nc], lists = the tests' cohort selections, S the raw
  * scores [n_rows x n_lists], mt / it the T-part statistics [n_lists x n_rows] of an earlier

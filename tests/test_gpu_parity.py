@@ -262,9 +262,64 @@ def test_adapt_s_norm_vs_oracle_large():
     ec = (rng.randn(ne, nc) * 8 - 14).astype(np.float32).astype(float)
     for nbest, disc in [(300, 0), (200, 17)]:
         ref = O.adapt_s_norm(sc, ct, ec, nbest, disc)
-        got = AdaptSNorm(nbest=nbest, nbest_discard=disc).predict(sc, ct, ec)
-        err = np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)
-        assert err.max() <= 2e-5, err.max()
+        for refine in (False, None):  # fp32 throughout (the fused kernels) / float64 where fp32 is not enough
+            got = AdaptSNorm(nbest=nbest, nbest_discard=disc, refine=refine).predict(sc, ct, ec)
+            err = np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)
+            assert err.max() <= 2e-5, err.max()
+
+
+def _refine_cases(ne, nt, nc, rng):
+    yield rng.randn(ne, nt) * 6 - 5, rng.randn(nc, nt) * 8 - 14, rng.randn(ne, nc) * 8 - 14
+    yield rng.randn(ne, nt) + 60, rng.randn(nc, nt) * 0.5 + 60, rng.randn(ne, nc) * 0.5 + 60  # narrow, far from zero
+    yield rng.standard_t(3, (ne, nt)) * 4, rng.standard_t(3, (nc, nt)) * 4 - 3, rng.standard_t(3, (ne, nc)) * 4 - 3
+    a, b, c = rng.randn(ne, 1) * 3, rng.randn(1, nt) * 3, rng.randn(nc) * 3  # a common factor per side, as PLDA scores have
+    yield (a + b + rng.randn(ne, nt) * 5 - 20, c[:, None] + b + rng.randn(nc, nt) * 5 - 20,
+           a + c[None, :] + rng.randn(ne, nc) * 5 - 20)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(60, 700, 2500, 300, 0), (33, 130, 22_000, 150, 4)])
+def test_adapt_s_norm_strict_relative(shape):
+    """float64 host arrays in, every normalised score within 1e-4 RELATIVE of the reference's float64
+    value, the ones that cancel to nearly zero included: entries whose fp32 error estimate is too large for
+    their magnitude are recomputed from the float64 matrices (hypmi_asnorm_refine).  Without the
+    refinement the same calls miss that bar on some entries, which is what makes the check meaningful.
+    The second shape takes the cohort in two segments."""
+    from hyperion_amd.score_norm import AdaptSNorm
+
+    ne, nt, nc, nbest, disc = shape
+    rng = np.random.RandomState(31)
+    missed = 0
+    for sc, ct, ec in _refine_cases(ne, nt, nc, rng):
+        ref = O.adapt_s_norm(sc, ct, ec, nbest, disc)
+        norm = AdaptSNorm(nbest=nbest, nbest_discard=disc)
+        got = norm.predict(sc, ct, ec)
+        rel = np.abs(got - ref) / np.abs(ref)
+        assert rel.max() <= 1e-4, float(rel.max())
+        assert 0 < norm.last_refined < ref.size // 2, norm.last_refined
+        plain = AdaptSNorm(nbest=nbest, nbest_discard=disc, refine=False)
+        rel32 = np.abs(plain.predict(sc, ct, ec) - ref) / np.abs(ref)
+        assert plain.last_refined is None
+        missed += int((rel32 > 1e-4).sum())
+    assert missed > 0
+
+
+@pytest.mark.gpu
+def test_adapt_s_norm_refine_needs_float64_host_arrays():
+    import torch
+
+    from hyperion_amd.score_norm import AdaptSNorm
+
+    rng = np.random.RandomState(1)
+    sc, ct, ec = rng.randn(5, 7), rng.randn(40, 7), rng.randn(5, 40)
+    norm = AdaptSNorm(nbest=10, refine=True)
+    with pytest.raises(ValueError):
+        norm.predict(sc.astype(np.float32), ct, ec)
+    with pytest.raises(ValueError):
+        norm.predict(torch.from_numpy(sc).cuda(), ct, ec)
+    with pytest.raises(ValueError):
+        norm.predict(sc, ct, ec, mask_coh_test=rng.rand(40, 7) > 0.1)
+    assert np.isfinite(norm.predict(sc, ct, ec)).all()
 
 
 @pytest.mark.parametrize("shape", [(37, 91, 640, 50, 0), (130, 70, 2100, 300, 3), (1100, 1200, 1030, 40, 0)])
@@ -833,10 +888,11 @@ def test_adapt_s_norm_cohort_larger_than_lds(masked):
     kw = {}
     if masked:
         kw = {"mask_coh_test": rng.rand(nc, nt) > 0.1, "mask_enr_coh": rng.rand(ne, nc) > 0.1}
-    got = AdaptSNorm(nbest=200, nbest_discard=3).predict(sc, ct, ec, **kw)
     ref = O.adapt_s_norm(sc, ct, ec, 200, 3, **kw)
-    err = np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)
-    assert err.max() <= 2e-5, float(err.max())
+    for refine in (False, None):
+        got = AdaptSNorm(nbest=200, nbest_discard=3, refine=refine).predict(sc, ct, ec, **kw)
+        err = np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)
+        assert err.max() <= 2e-5, float(err.max())
 
 
 @pytest.mark.gpu
