@@ -62,12 +62,19 @@ constexpr int TK_CAND = 64;  // boundary candidates re-decided per boundary
 // ITEMS registers (no LDS copy of the row, no atomics on it).  The key at descending rank `want` is
 // found bit by bit from the top: the answer has bit b set iff more than `want` keys are
 // >= (prefix | 1 << b).  One step is ITEMS compares per thread, a ballot count per wave and one
-// barrier.  As soon as at most TR_CAND keys are left inside the bracket [prefix, prefix + 2^b) they are
-// copied to LDS, every wave takes all of them (TR_CAND / 64 registers per lane) and finishes the
-// remaining bits on its own without barriers.  (512 measured best for 20 000-member rows: 1024 doubles
-// the compares of the ~28 remaining steps, 256 costs two more full passes and more often leaves the
-// uncertainty band of the boundary outside the bracket.)  Several such workgroups share a CU, so the
-// barriers of one overlap the compares of the others.
+// barrier; a step whose threshold lies outside the row's range of keys (known from one pass of three-input
+// minima and maxima) is decided without looking at the keys.  As soon as at most TR_CAND keys are left
+// inside the bracket [prefix, prefix + 2^b) they are appended to an array in LDS (a place per key from an
+// LDS counter), one wave takes all of them (TR_CAND / 64 registers per lane), finishes the remaining bits
+// on its own without barriers -- stopping as soon as a single key is left -- and hands the result to the
+// others.  (512 measured best for 20 000-member rows: 1024 doubles the compares of the remaining steps,
+// 256 costs two more full passes and more often leaves the uncertainty band of the boundary outside the
+// bracket.)  Several such workgroups share a CU, so the barriers of one overlap the compares of the
+// others.  The kernel is bound by vector-instruction issue (about 70 % of the cycles), so the work per
+// key is counted in instructions: row loads through a buffer descriptor with scalar offsets (none), the
+// order-preserving key in four (key_of_min1), a range check only for the last items of a thread
+// (topk_safe_items), one compare per step, two per key for the candidate test, two for the membership bit
+// (shift_in4_ge).
 constexpr int TR_THREADS = 256;    // threads per row of up to 24 576 members, twice as many above
 constexpr int TR_MAX_WAVES = 8;
 constexpr int TR_CAND = 512;     // the bracket is narrow once it holds at most this many keys
@@ -77,6 +84,8 @@ constexpr int TR_MAX_NC = 128 * 512;  // longest row: 512 threads with 128 keys 
 
 struct TopkShared {
     unsigned cnt[2][TR_MAX_WAVES];         // per-wave counters, alternating between steps
+    unsigned ext[2][TR_MAX_WAVES];         // per-wave smallest and largest key
+    unsigned res[8];                       // what the wave that finished a selection found
     unsigned ncand;                        // candidates written so far / boundary candidates
     unsigned cand[TR_CAND]; // keys inside the bracket
 };
@@ -97,7 +106,7 @@ __device__ __forceinline__ int block_sum(TopkShared& sh, int& par, unsigned wave
         sum += (v.x + v.y) + (v.z + v.w);
     }
     par ^= 1;
-    return (int)sum;
+    return __builtin_amdgcn_readfirstlane((int)sum);  // the same in every lane: the callers branch on it
 }
 
 // Makes the compiler forget what it knows about x (no instruction): keeps it from carrying dozens of
@@ -121,6 +130,70 @@ __device__ __forceinline__ unsigned mask_count(unsigned long long m) {
     unsigned c;
     asm volatile("s_bcnt1_i32_b64 %0, %1" : "=s"(c) : "s"(m) : "scc");
     return c;
+}
+
+// key_of(x) raised to at least 1 (key 0 stands for "no element"), in four instructions without a
+// compare: the compiler's own sequence takes five and a wait between its compare and its select.
+__device__ __forceinline__ unsigned key_of_min1(float f) {
+    unsigned k;
+    asm("v_ashrrev_i32 %0, 31, %1\n\tv_or_b32 %0, 0x80000000, %0\n\tv_xor_b32 %0, %1, %0\n\tv_max_u32 %0, 1, %0"
+        : "=&v"(k)
+        : "v"(f));
+    return k;
+}
+
+// bits = bits << 4 | (k3 >= kb) << 3 | (k2 >= kb) << 2 | (k1 >= kb) << 1 | (k0 >= kb): every compare
+// result enters as the carry of bits + bits, so a membership bit costs two vector instructions; the four
+// compares stand in front of the four additions because a vector instruction may read a scalar register
+// only two instructions after the vector instruction that wrote it.
+__device__ __forceinline__ unsigned shift_in4_ge(unsigned bits, unsigned k3, unsigned k2, unsigned k1, unsigned k0,
+                                                 unsigned kb) {
+    unsigned long long m0, m1, m2, m3;
+    asm("v_cmp_ge_u32_e64 %1, %5, %9\n\t"
+        "v_cmp_ge_u32_e64 %2, %6, %9\n\t"
+        "v_cmp_ge_u32_e64 %3, %7, %9\n\t"
+        "v_cmp_ge_u32_e64 %4, %8, %9\n\t"
+        "v_addc_co_u32_e64 %0, %1, %0, %0, %1\n\t"
+        "v_addc_co_u32_e64 %0, %2, %0, %0, %2\n\t"
+        "v_addc_co_u32_e64 %0, %3, %0, %0, %3\n\t"
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %4"
+        : "+v"(bits), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+        : "v"(k3), "v"(k2), "v"(k1), "v"(k0), "s"(kb));
+    return bits;
+}
+
+// The lanes named by four masks append their keys to an array in LDS: every such lane adds 4 to the word at
+// cnt_addr (which starts at the array's address) and stores its key where the sum stood before.  The four
+// atomics are in flight together; the execution mask is set per instruction and restored.
+__device__ __forceinline__ void append4(unsigned cnt_addr, unsigned long long m0, unsigned long long m1,
+                                        unsigned long long m2, unsigned long long m3, unsigned k0, unsigned k1,
+                                        unsigned k2, unsigned k3) {
+    unsigned s0, s1, s2, s3;
+    unsigned long long save;
+    const unsigned four = 4;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "s_mov_b64 exec, %[m0]\n\tds_add_rtn_u32 %[s0], %[ca], %[four]\n\t"
+        "s_mov_b64 exec, %[m1]\n\tds_add_rtn_u32 %[s1], %[ca], %[four]\n\t"
+        "s_mov_b64 exec, %[m2]\n\tds_add_rtn_u32 %[s2], %[ca], %[four]\n\t"
+        "s_mov_b64 exec, %[m3]\n\tds_add_rtn_u32 %[s3], %[ca], %[four]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "ds_write_b32 %[s3], %[k3]\n\t"
+        "s_mov_b64 exec, %[m2]\n\tds_write_b32 %[s2], %[k2]\n\t"
+        "s_mov_b64 exec, %[m1]\n\tds_write_b32 %[s1], %[k1]\n\t"
+        "s_mov_b64 exec, %[m0]\n\tds_write_b32 %[s0], %[k0]\n\t"
+        "s_mov_b64 exec, %[save]"
+        : [save] "=&s"(save), [s0] "=&v"(s0), [s1] "=&v"(s1), [s2] "=&v"(s2), [s3] "=&v"(s3)
+        : [m0] "s"(m0), [m1] "s"(m1), [m2] "s"(m2), [m3] "s"(m3), [ca] "v"(cnt_addr), [four] "v"(four), [k0] "v"(k0),
+          [k1] "v"(k1), [k2] "v"(k2), [k3] "v"(k3)
+        : "memory");
+}
+
+// Items of a thread whose cohort index is inside the row for every row the (ITEMS, THREADS) variant is
+// launched for (launch_topk_reg checks it): no range check is compiled for them.
+constexpr int topk_safe_items(int items, int threads) {
+    if (threads == 256) return items <= 4 ? 0 : items <= 8 ? 4 : items <= 16 ? 8 : items - 16;
+    return items - (items <= 96 ? 16 : 32);
 }
 
 // number of set bits of m below this lane
@@ -153,9 +226,45 @@ struct TopkRegs {
         return c;
     }
 
-    // Key T at descending rank `want` (0-based), the number of keys > T and the number == T.
-    __device__ __forceinline__ void select(int want, int nc, TopkShared& sh, int& par, int tid, unsigned* out_key,
-                                           int* out_gt, int* out_eq, BandProbe* band = nullptr) {
+    // Smallest and largest real key of the row (key 0, "no element", can only stand in items >= SAFE).
+    // Two keys per instruction and extreme (v_min3 / v_max3), one barrier.
+    template <int SAFE>
+    __device__ __forceinline__ void extremes(TopkShared& sh, int tid, unsigned* kmin, unsigned* kmax) const {
+        const int lane = tid & 63, wave = tid >> 6;
+        unsigned hi = 0, lo = 0xffffffffu, lo1 = 0xffffffffu;  // lo1: min of key - 1 over the items that may be 0
+#pragma unroll
+        for (int j = 0; j < ITEMS; j += 2) {
+            hi = max(max(hi, key[j]), key[j + 1]);
+            if (j + 1 < SAFE) lo = min(min(lo, key[j]), key[j + 1]);
+            else lo1 = min(min(lo1, key[j] - 1u), key[j + 1] - 1u);
+        }
+        if (lo1 != 0xffffffffu) lo = min(lo, lo1 + 1u);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            hi = max(hi, (unsigned)__shfl_xor((int)hi, off, 64));
+            lo = min(lo, (unsigned)__shfl_xor((int)lo, off, 64));
+        }
+        if (lane == 0) {
+            sh.ext[0][wave] = lo;
+            sh.ext[1][wave] = hi;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < THREADS / 64; ++w) {
+            lo = min(lo, sh.ext[0][w]);
+            hi = max(hi, sh.ext[1][w]);
+        }
+        *kmin = (unsigned)__builtin_amdgcn_readfirstlane((int)lo);
+        *kmax = (unsigned)__builtin_amdgcn_readfirstlane((int)hi);
+    }
+
+    // Key T at descending rank `want` (0-based), the number of keys > T and the number == T.  kmin / kmax:
+    // the row's extreme keys -- a step whose threshold lies above the largest key counts nothing and one
+    // whose threshold lies at or below the smallest counts everything, neither looks at the keys (the
+    // exponent bits that all of a row's candidates share are most of the steps of the first phase).
+    __device__ __forceinline__ void select(int want, int nc, unsigned kmin, unsigned kmax, TopkShared& sh, int& par,
+                                           int tid, unsigned* out_key, int* out_gt, int* out_eq,
+                                           BandProbe* band = nullptr) {
         if (band) band->known = false;
         const int lane = tid & 63, wave = tid >> 6;
         unsigned prefix = 0;
@@ -165,7 +274,13 @@ struct TopkRegs {
         for (; b >= 0; --b) {
             if (c_lo - c_hi <= TR_CAND && b < 31) break;
             const unsigned cand = prefix | (1u << b);
-            const int c = block_sum<THREADS / 64>(sh, par, wave_count([cand](unsigned kx) { return kx >= cand; }), lane, wave);
+            int c;
+            if (cand > kmax)
+                c = 0;
+            else if (cand <= kmin)
+                c = nc;
+            else
+                c = block_sum<THREADS / 64>(sh, par, wave_count([cand](unsigned kx) { return kx >= cand; }), lane, wave);
             if (c > want) {
                 prefix = cand;
                 c_lo = c;
@@ -177,29 +292,31 @@ struct TopkRegs {
             // bracket [prefix, prefix + 2^(b+1)) holds c_lo - c_hi <= TR_CAND keys: move them to registers
             const unsigned width = b == 31 ? 0u : (1u << (b + 1));  // b < 31 here
             const unsigned bracket_lo = prefix;
-            if (tid == 0) sh.ncand = 0;
-            __syncthreads();
             // one compare per key: the bracket is aligned, so key 0 ("no element") falls outside it unless
             // it starts at 0, in which case it starts at 1 instead
             const unsigned first_key = prefix == 0 ? 1u : prefix, span = width - (first_key - prefix);
             auto inside = [first_key, span](unsigned kx) { return kx - first_key < span; };
-            const unsigned mine = wave_count(inside);
-            unsigned at = 0;
-            if (lane == 0) at = atomicAdd(&sh.ncand, mine);  // one slot range per wave
-            at = __shfl(at, 0, 64);
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) opaque(key[j]);  // recompute the ballots rather than keep ITEMS masks
-#pragma unroll
-            for (int j = 0; j < ITEMS; ++j) {
-                const bool in = inside(key[j]);
-                const unsigned long long m = __ballot(in);
-                if (in) sh.cand[at + lanes_below(m)] = key[j];
-                at += mask_count(m);
-            }
+            // Every candidate takes its place from a counter in LDS and is written there (append4): two
+            // vector instructions per key (the subtraction and the compare) instead of the five of a ballot
+            // compaction.  The places depend on the order the atomics arrive in, the set of candidates --
+            // all that the later steps look at -- does not.  The counter starts at the array's own address.
+            const unsigned cand_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)sh.cand;
+            const unsigned cnt_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)&sh.ncand;
+            if (tid == 0) sh.ncand = cand_addr;
             __syncthreads();
-            // Every wave now takes ALL candidates (TR_CAND / 64 per lane) and finishes the remaining
-            // bits on its own: same data, same result in every wave, no barrier and no LDS per step.
+#pragma unroll
+            for (int j = 0; j < ITEMS; j += 4)
+                append4(cnt_addr, __ballot(inside(key[j])), __ballot(inside(key[j + 1])), __ballot(inside(key[j + 2])),
+                        __ballot(inside(key[j + 3])), key[j], key[j + 1], key[j + 2], key[j + 3]);
+            // the compiler does not see the stores inside append4 and would let the barrier overtake them
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            // One wave takes all candidates (TR_CAND / 64 per lane) and finishes the remaining bits on its
+            // own, without barriers or LDS traffic per step; the others wait for its result (every wave
+            // doing the same steps, as before, spent four times the vector instructions on them).  The wave
+            // changes from row to row, so that the rows a CU works on do not all load the same SIMD.
             const int n_in = c_lo - c_hi;
+            if (__builtin_amdgcn_readfirstlane(wave) == (int)(blockIdx.x & (THREADS / 64 - 1))) {
             unsigned ck[TR_CAND / 64];
 #pragma unroll
             for (int u = 0; u < TR_CAND / 64; ++u) {
@@ -208,6 +325,18 @@ struct TopkRegs {
             }
             const int above = c_hi;  // keys above the bracket as it was when the candidates were copied
             for (; b >= 0; --b) {
+                if (c_lo - c_hi == 1) {
+                    // One key left in the bracket [prefix, prefix + 2^(b+1)): it is the answer, and its
+                    // remaining bits (about fourteen steps for distinct keys) need not be found one by one.
+                    const unsigned w_now = 2u << b, first_now = prefix == 0 ? 1u : prefix;
+                    unsigned mine = 0;
+#pragma unroll
+                    for (int u = 0; u < TR_CAND / 64; ++u)
+                        if (ck[u] >= first_now && ck[u] - prefix < w_now) mine = ck[u];
+                    const unsigned long long holder = __ballot(mine != 0);
+                    prefix = (unsigned)__builtin_amdgcn_readlane((int)mine, __builtin_ctzll(holder));
+                    break;  // c_hi keys lie above it, c_lo = c_hi + 1 at or above
+                }
                 const unsigned cand = prefix | (1u << b);
                 unsigned wc = 0;
 #pragma unroll
@@ -240,6 +369,22 @@ struct TopkRegs {
                 }
                 band->in_band = (int)wb;
             }
+            if (lane == 0) {
+                sh.res[0] = prefix;
+                sh.res[1] = (unsigned)c_lo;
+                sh.res[2] = (unsigned)c_hi;
+                sh.res[3] = band && band->known ? 1u : 0u;
+                sh.res[4] = band ? (unsigned)band->in_band : 0u;
+            }
+            }
+            __syncthreads();
+            prefix = (unsigned)__builtin_amdgcn_readfirstlane((int)sh.res[0]);
+            c_lo = __builtin_amdgcn_readfirstlane((int)sh.res[1]);
+            c_hi = __builtin_amdgcn_readfirstlane((int)sh.res[2]);
+            if (band) {
+                band->known = __builtin_amdgcn_readfirstlane((int)sh.res[3]) != 0;
+                band->in_band = __builtin_amdgcn_readfirstlane((int)sh.res[4]);
+            }
         }
         *out_key = prefix;
         *out_gt = c_hi;          // keys >= prefix + 1
@@ -263,23 +408,29 @@ __device__ __forceinline__ void topk_rows_reg_body(const float* __restrict__ A, 
     __shared__ unsigned short bank_start[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t xrow = blockIdx.x;  // row of the exact values and bounds
-    const int64_t row = ex.row_map ? ex.row_map[xrow] : xrow;
+    const int64_t row = ex.row_map ? (int64_t)__builtin_amdgcn_readfirstlane(ex.row_map[xrow]) : xrow;
     int par = 0;
     TopkRegs<ITEMS, THREADS> R;
     const float* src = A + row * lda;
-    // All loads of the row are issued before the first use (clamped index, no branch per item).
+    // All loads of the row are issued before the first use, through a buffer descriptor of the row: the
+    // address of an item that lies inside the row for every lane is the lane's byte offset plus a scalar,
+    // so its load costs no vector instruction; the last items carry their offset in the lane's own (the
+    // range check covers the vector offset only) and read zero behind the end of the row instead of the
+    // next row or unmapped memory.
     // Key 0 is reserved for "no element": real keys are at least 1 (only the all-ones NaN maps lower).
     {
+        constexpr int SAFE = topk_safe_items(ITEMS, THREADS);
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, nc * 4, 0x00020000);
         float raw[ITEMS];
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const int i = j * THREADS + tid;
-            raw[j] = __builtin_nontemporal_load(src + (i < nc ? i : nc - 1));
-        }
+        for (int j = 0; j < ITEMS; ++j)
+            raw[j] = __uint_as_float(j < SAFE ? __builtin_amdgcn_raw_buffer_load_b32(rs, tid * 4, j * THREADS * 4, 2)
+                                              : __builtin_amdgcn_raw_buffer_load_b32(rs, (j * THREADS + tid) * 4, 0, 2));  // 2: non-temporal
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
-            const unsigned kx = key_of(raw[j]);
-            R.key[j] = j * THREADS + tid < nc ? (kx == 0 ? 1u : kx) : 0u;
+            const unsigned kx = key_of_min1(raw[j]);
+            R.key[j] = j < SAFE || j * THREADS + tid < nc ? kx : 0u;
         }
     }
 
@@ -294,8 +445,10 @@ __device__ __forceinline__ void topk_rows_reg_body(const float* __restrict__ A, 
             probe_hi.bound = probe_lo.bound =
                 ex.err_coeff * (ex.bnd_rows[2 * xrow] * ex.coh_gmax + ex.bnd_rows[2 * xrow + 1] + ex.coh_qmax);
     }
-    R.select(last - 1, nc, sh, par, tid, &key_hi, &gt_hi, &eq_hi, &probe_hi);
-    if (use_lo) R.select(discard - 1, nc, sh, par, tid, &key_lo, &gt_lo, &eq_lo, &probe_lo);
+    unsigned kmin, kmax;
+    R.template extremes<topk_safe_items(ITEMS, THREADS)>(sh, tid, &kmin, &kmax);
+    R.select(last - 1, nc, kmin, kmax, sh, par, tid, &key_hi, &gt_hi, &eq_hi, &probe_hi);
+    if (use_lo) R.select(discard - 1, nc, kmin, kmax, sh, par, tid, &key_lo, &gt_lo, &eq_lo, &probe_lo);
 
     // what fp32 cannot resolve around a boundary value: re-decide those entries from float64 values
     int n_hi = 0, n_lo = 0;
@@ -465,8 +618,8 @@ __device__ __forceinline__ void topk_rows_reg_body(const float* __restrict__ A, 
         for (int w = 0; w < SELW; ++w) {
             unsigned bits = 0;
 #pragma unroll
-            for (int j = (32 * w + 31 < ITEMS ? 32 * w + 31 : ITEMS - 1); j >= 32 * w; --j)
-                bits = (bits << 1) | (R.key[j] >= kb ? 1u : 0u);
+            for (int j = (32 * w + 31 < ITEMS ? 32 * w + 31 : ITEMS - 1); j >= 32 * w; j -= 4)
+                bits = shift_in4_ge(bits, R.key[j], R.key[j - 1], R.key[j - 2], R.key[j - 3], kb);
             above_hi[w] = bits;
             valid[w] = 0xffffffffu;
         }
@@ -600,8 +753,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
 }
 
 template <int ITEMS, int THREADS = TR_THREADS>
-void launch_topk_reg(const float* A, int64_t n_rows, int nc, int64_t lda, int k, int discard, uint16_t* idx_t,
+int launch_topk_reg(const float* A, int64_t n_rows, int nc, int64_t lda, int k, int discard, uint16_t* idx_t,
                      int64_t ldi, const ExactSrc& ex, hipStream_t stream) {
+    static_assert(ITEMS % 4 == 0, "the membership bits are made four items at a time");
+    HYPMI_REQUIRE(nc > topk_safe_items(ITEMS, THREADS) * THREADS && nc <= ITEMS * THREADS,
+                  "topk_rows: variant <%d, %d> does not take rows of %d", ITEMS, THREADS, nc);
     // as many waves per SIMD as the keys leave registers for without spilling
     if constexpr (ITEMS <= 80)
         hipLaunchKernelGGL((topk_rows_reg_kernel_w4<ITEMS, THREADS>), dim3((unsigned)n_rows), dim3(THREADS), 0, stream,
@@ -612,6 +768,7 @@ void launch_topk_reg(const float* A, int64_t n_rows, int nc, int64_t lda, int k,
     else
         hipLaunchKernelGGL((topk_rows_reg_kernel<ITEMS, THREADS>), dim3((unsigned)n_rows), dim3(THREADS), 0, stream, A,
                            lda, nc, k, discard, idx_t, ldi, ex);
+    return HYPMI_OK;
 }
 
 // R rows of X per workgroup, held in LDS interleaved (xr[c * R + rr]); lanes over lists q.
@@ -1763,23 +1920,25 @@ extern "C" int hypmi_topk_rows(const float* A, int64_t n_rows, int nc, int64_t l
     // (up to 80 keys each still run four waves per SIMD; 65 536 rows of 40 960 members: 7.6 ms
     // with 160 keys in each of 256 threads, one wave per SIMD; 3.6 ms with 80 in each of 512).  More threads
     // at the same keys per thread do not pay: 20 000 members take 1.33 ms with 256 threads, 1.81 with 512.
+    int rc = HYPMI_OK;
     if (nc <= 96 * 256) {
         const int items = (nc + TR_THREADS - 1) / TR_THREADS;
 #define HYPMI_TOPK_CASE(N) \
-    if (items <= N) { launch_topk_reg<N>(A, n_rows, nc, lda, k, discard, idx_t, ldi, ex, stream); } else
+    if (items <= N) { rc = launch_topk_reg<N>(A, n_rows, nc, lda, k, discard, idx_t, ldi, ex, stream); } else
         HYPMI_TOPK_CASE(4) HYPMI_TOPK_CASE(8) HYPMI_TOPK_CASE(16) HYPMI_TOPK_CASE(32) HYPMI_TOPK_CASE(48)
         HYPMI_TOPK_CASE(64) HYPMI_TOPK_CASE(80)
-        { launch_topk_reg<96>(A, n_rows, nc, lda, k, discard, idx_t, ldi, ex, stream); }
+        { rc = launch_topk_reg<96>(A, n_rows, nc, lda, k, discard, idx_t, ldi, ex, stream); }
 #undef HYPMI_TOPK_CASE
     } else if (nc <= 64 * 512) {
-        launch_topk_reg<64, 512>(A, n_rows, nc, lda, k, discard, idx_t, ldi, ex, stream);
+        rc = launch_topk_reg<64, 512>(A, n_rows, nc, lda, k, discard, idx_t, ldi, ex, stream);
     } else if (nc <= 80 * 512) {
-        launch_topk_reg<80, 512>(A, n_rows, nc, lda, k, discard, idx_t, ldi, ex, stream);
+        rc = launch_topk_reg<80, 512>(A, n_rows, nc, lda, k, discard, idx_t, ldi, ex, stream);
     } else if (nc <= 96 * 512) {  // (1024 threads with 48 or 64 keys each are no faster than these two)
-        launch_topk_reg<96, 512>(A, n_rows, nc, lda, k, discard, idx_t, ldi, ex, stream);
+        rc = launch_topk_reg<96, 512>(A, n_rows, nc, lda, k, discard, idx_t, ldi, ex, stream);
     } else if (nc <= TR_MAX_NC) {
-        launch_topk_reg<128, 512>(A, n_rows, nc, lda, k, discard, idx_t, ldi, ex, stream);
+        rc = launch_topk_reg<128, 512>(A, n_rows, nc, lda, k, discard, idx_t, ldi, ex, stream);
     }
+    if (rc != HYPMI_OK) return rc;
     HYPMI_HIP(hipGetLastError());
     return HYPMI_OK;
 }

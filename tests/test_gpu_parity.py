@@ -853,6 +853,36 @@ def test_topk_rows_matches_stable_argsort(n, nc, k, disc, shift):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,nc,k,disc,scale,shift", [
+    (20000, 900, 50, 0, 3.0, 0.0), (4000, 20000, 300, 2, 5.0, -8.0), (3000, 12000, 300, 0, 0.5, 40.0),
+    (3000, 20000, 300, 0, 25.0, -60.0)])
+def test_topk_rows_many_rows(n, nc, k, disc, scale, shift):
+    """Thousands of rows, so that every CU runs several workgroups of the selection at once (a handful of
+    rows never has two of them share a CU, and an ordering fault between the waves of a workgroup only shows
+    under that load): every row against a stable descending argsort, twice with identical lists.  The score
+    distributions put the selection boundary at positive values, among negative ones, and in a narrow band
+    far from zero (where most of the first steps are decided from the row's extreme values alone)."""
+    import torch
+
+    from hyperion_amd.score_norm.adapt_s_norm import lists_to_numpy, topk_rows
+
+    rng = np.random.default_rng(n + nc)
+    A = rng.standard_normal((n, nc), dtype=np.float32) * np.float32(scale) + np.float32(shift)
+    Ad = torch.from_numpy(A).cuda()
+    lists = topk_rows(Ad, k, disc)
+    idx = np.sort(lists_to_numpy(lists, k), axis=1)
+    again = topk_rows(Ad, k, disc)
+    assert torch.equal(lists, again)
+    part = np.argpartition(-A, (disc, disc + k - 1), axis=1)[:, disc:disc + k] if disc else \
+        np.argpartition(-A, k - 1, axis=1)[:, :k]
+    want = np.sort(part, axis=1)
+    bad = np.nonzero((idx != want).any(axis=1))[0]
+    for r in bad:  # argpartition picks any of the members tied at a boundary: settle those rows by a stable sort
+        order = np.argsort(-A[r], kind="stable")
+        assert np.array_equal(idx[r], np.sort(order[disc:disc + k])), int(r)
+
+
+@pytest.mark.gpu
 def test_topk_lists_are_ordered_by_bank_class():
     """Lists of up to 2048 members leave the top-k kernel ordered by (index mod 32), inside a class by
     (index mod 256, index) -- the thread that held the member, then its item --, rotated by
