@@ -181,6 +181,7 @@ class PLDABackend:
         # fit per chunk of tests the enrolment rows are walked in blocks, so that the chunk of tests can
         # stay long (every workgroup of the statistics kernels amortises its rows over the lists of one tile)
         self.tile_bytes = 96 << 30
+        self.trials_before_topk = True  # order of a chunk's launches, see score_snorm
         # operands of the score kernel: "pair" (scaled fp16 pairs, the default), "triple" (exact bf16 triples)
         # or None: fp32 packed rows on the fp32 matrix cores
         self.split_format = engine.DEFAULT_SPLIT
@@ -380,13 +381,23 @@ class PLDABackend:
                     Gt64, bt = self.plan.prologue_f64(engine.upload64(x_test[c0:c1]), SIDE_ENROL)
                     return dict(cohort["coh64"], G_rows=Gt64, bnd_rows=bt)
                 exact = T("prologue_f64", f64_rows)
+            # The matrix-core kernels of a chunk stand together at its start: each of them pulls the clock down,
+            # and whatever starts behind one runs its first half millisecond at that clock -- with the trial
+            # scores (one enrolment block) in front of the selection only the selection, which mostly waits for
+            # memory, starts at the low clock, and both gathers run at the full one.
+            S_first = None
+            if self.trials_before_topk and eb >= ne:
+                S_first = T("score_trials", lambda: engine.score(Ge, Gt_cols, split=False))           # [enrol, chunk]
             t_idx = T("topk_test", lambda: topk_rows(A_tc, k, self.nbest_discard, exact))  # [k, chunk]
             nq = c1 - c0
             for e0 in range(0, ne, eb):
                 e1 = min(ne, e0 + eb)
-                # the trial scores before the two gathers: the score kernel pulls the clock down, and a gather
-                # that starts behind it runs its first half millisecond at that clock
-                S = T("score_trials", lambda: engine.score(_rows(Ge, e0, e1), Gt_cols, split=False))   # [enrol, chunk]
+                # (several enrolment blocks: the trial scores of a block before its two gathers, so that no
+                # matrix-core kernel runs between them)
+                if S_first is not None:
+                    S, S_first = S_first, None
+                else:
+                    S = T("score_trials", lambda: engine.score(_rows(Ge, e0, e1), Gt_cols, split=False))
                 paired = fused and (self.pair_stats or segmented)
                 if paired:
                     mt, ldt = T("gather_t", lambda: gather_stats_pairs(A_tc, e_idx[:, e0:e1], e1 - e0, 1e-5, k),
