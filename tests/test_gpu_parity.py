@@ -883,6 +883,56 @@ def test_topk_rows_many_rows(n, nc, k, disc, scale, shift):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nc,k,disc", [(900, 50, 0), (900, 40, 3), (5000, 300, 0), (20000, 300, 0), (20000, 300, 2),
+                                       (30000, 300, 0)])
+def test_topk_rows_sign_and_range_cases(nc, k, disc):
+    """Rows whose scores are all positive, all negative, all of one exponent, of both signs with the boundary
+    just above or just below zero, with signed zeros, infinities, tiny and huge magnitudes, and with fewer
+    positive scores than the selection holds: the selection decides the steps of the sign bit and of shared
+    exponent bits from the row's range alone, so every combination of ranges has to give the members a stable
+    descending argsort gives (-0.0 below +0.0 as keys: no row here has both at a boundary).  A last row holds
+    the all-ones bit pattern, the NaN whose order-preserving key is the one the selection reserves for "no
+    element": the row must still select k distinct members inside the row."""
+    import torch
+
+    from hyperion_amd.score_norm.adapt_s_norm import lists_to_numpy, topk_rows
+
+    rng = np.random.default_rng(nc + k + disc)
+    z = rng.standard_normal((14, nc)).astype(np.float32)
+    rows = [
+        np.abs(z[0]) + 0.5,                         # all positive
+        -np.abs(z[1]) - 0.5,                        # all negative
+        1.0 + 0.5 * rng.random(nc, dtype=np.float32),   # one exponent
+        -(1.0 + 0.5 * rng.random(nc, dtype=np.float32)),
+        z[4] * 3 - 6.0,                             # few positives: boundary positive for small k only
+        z[5] * 3 + 6.0,                             # few negatives
+        z[6] * 1e-30,                               # tiny magnitudes of both signs
+        z[7] * 1e30,
+        np.where(z[8] > 1.5, z[8], np.float32(-0.0)).astype(np.float32),   # most of the row -0.0
+        np.where(z[9] > 2.5, z[9], z[9] * 1e-20).astype(np.float32),
+        z[10].copy(), z[11].copy(), z[12].copy(),
+    ]
+    rows[10][::97] = np.inf
+    rows[10][5::89] = -np.inf
+    npos = k + disc - 3                             # fewer positive scores than discard + k
+    rows[11] = -np.abs(rows[11]) - 1e-3
+    rows[11][rng.choice(nc, npos, replace=False)] = np.abs(z[13][:npos]) + 1e-3
+    rows[12] = np.abs(rows[12]) + 1e-3
+    rows[12][rng.choice(nc, nc - (k + disc + 3), replace=False)] *= -1   # a few more positives than discard + k
+    A = np.stack(rows).astype(np.float32)
+    last = rng.standard_normal(nc).astype(np.float32)
+    last.view(np.uint32)[[3, nc // 2, nc - 1]] = 0xFFFFFFFF
+    A = np.concatenate([A, last[None]], axis=0)
+    idx = lists_to_numpy(topk_rows(torch.from_numpy(A).cuda(), k, disc), k)
+    order = np.argsort(-A[:-1], axis=1, kind="stable")
+    want = np.sort(order[:, disc:disc + k], axis=1)
+    got = np.sort(idx[:-1], axis=1)
+    for r in range(got.shape[0]):
+        assert np.array_equal(got[r], want[r]), r
+    assert len(set(idx[-1].tolist())) == k and idx[-1].max() < nc
+
+
+@pytest.mark.gpu
 def test_topk_lists_are_ordered_by_bank_class():
     """Lists of up to 2048 members leave the top-k kernel ordered by (index mod 32), inside a class by
     (index mod 256, index) -- the thread that held the member, then its item --, rotated by
