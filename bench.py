@@ -465,7 +465,7 @@ def fp32_only_stage(plda, preproc, cfg):
 
 # ms per step of the default workload on the boxes it has been measured on with one tree (same command):
 # boxes differ by this much in every stage, so differences between runs below it say nothing
-BOX_SPREAD_NOTE = "same tree, same command on different MI355X boxes: 584-625 ms per step (7 %)"
+BOX_SPREAD_NOTE = "same tree, same command on different MI355X boxes: 576-625 ms per step (8 %)"
 
 
 def main_asnorm(args, cfg, chain, model, plda, preproc, world, rank, dist):

@@ -65,7 +65,7 @@ def flat(prefix, m):
 
 
 def gen_selfcheck():
-    """Known answers printed by the survey session (loader self-check)."""
+    """Known answers recorded from an earlier run of the reference on the same seeds (loader self-check)."""
     rng = np.random.RandomState(0)
     d, yd = 16, 4
     V = rng.randn(yd, d)

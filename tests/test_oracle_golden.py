@@ -27,7 +27,7 @@ def test_llr_1vs1(golden, kind, tag):
 
 
 def test_known_answers():
-    """Values printed by the reference in the survey session for seeded toy models."""
+    """Values the reference printed for seeded toy models in an earlier run of it."""
     rng = np.random.RandomState(0)
     d, yd = 16, 4
     V = rng.randn(yd, d)
