@@ -43,7 +43,8 @@ WORKLOADS = {
     # one GPU's share of the 1M x 1M matrix on 8 GPUs (125 000 tests per GPU: `--gpus 8` is the whole
     # job); the normalised scores are never kept, every block goes into target / non-target histograms
     "asnorm_1m_125k": dict(n_enrol=1_000_000, n_test=125_000, d=512, lda=200, K=150, n_coh=20_000, nbest=300,
-                           sink=True, test_chunk=65536),  # (16 384: 6.74 s per step, 32 768: 6.63, 65 536: 6.60)
+                           sink=True, test_chunk=32768),  # (16 384: 6.74 s per warm step, 32 768: 6.63, 65 536: 6.60
+    # -- but a cold first step, which is what the default line's stage times, pays 1.4 s for its larger buffers)
     "asnorm_100k_16k": dict(n_enrol=100_000, n_test=16_384, d=512, lda=200, K=150, n_coh=20_000, nbest=300,
                             sink=True, test_chunk=32768),
     "asnorm_tiny": dict(n_enrol=300, n_test=2_000, d=512, lda=200, K=150, n_coh=1_000, nbest=100),
@@ -312,6 +313,7 @@ def asnorm_run(plda, preproc, cfg, steps, warmup, rank, world, dist, split_forma
         dist.barrier()
     torch.cuda.synchronize()
     be.trace = []  # HIP events around the launches of the timed steps (on the stream they run on)
+    gather_clock(reset=True)  # (before the timed region: it synchronises)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -321,6 +323,7 @@ def asnorm_run(plda, preproc, cfg, steps, warmup, rank, world, dist, split_forma
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     trace, be.trace = be.trace, None
+    ghz = gather_clock()
     per = {}
     for name, e0, e1, shape in trace:
         per.setdefault(name, []).append((e0.elapsed_time(e1), shape))
@@ -331,7 +334,7 @@ def asnorm_run(plda, preproc, cfg, steps, warmup, rank, world, dist, split_forma
         avg_ms = float(np.mean([ms for ms, _ in g]))
         avg_bytes = float(np.mean([4.0 * r * q * k for _, (r, q, k) in g]))
         st["gather"] = {"launches_per_step": len(g) // steps, "avg_launch_ms": avg_ms,
-                        "algorithmic_bytes_per_launch": avg_bytes}
+                        "algorithmic_bytes_per_launch": avg_bytes, "shader_clock_ghz": ghz}
     if sink:
         h = hists[0]
         m = h.moments()
@@ -340,6 +343,17 @@ def asnorm_run(plda, preproc, cfg, steps, warmup, rank, world, dist, split_forma
     else:
         st["checksum"] = float(out.sum(dtype=torch.float64).item())
     return dt, st, be, (xe, xc, xt, out)
+
+
+def gather_clock(reset=False):
+    """Shader clock (GHz) the LDS-resident gather kernels have run at since the last reset (None if none ran)."""
+    import ctypes
+
+    from hyperion_amd import _lib
+
+    ghz = ctypes.c_double(0.0)
+    _lib.check(_lib.load().hypmi_gather_clock(ctypes.byref(ghz), 1 if reset else 0))
+    return float(ghz.value) or None
 
 
 def asnorm_check(be, bufs, chain, model, cfg, n_rows=64, n_cols=2048):
@@ -510,12 +524,15 @@ def main_asnorm(args, cfg, chain, model, plda, preproc, world, rank, dist):
             "unit": "GB/s", "frac": ach / LDS_PEAK_GBS, "traffic": profiled_traffic(args.workload),
             "avg_launch_ms": g["avg_launch_ms"], "launches_per_step": g["launches_per_step"],
             "algorithmic_bytes_per_launch": g["algorithmic_bytes_per_launch"],
+            "shader_clock_ghz": g.get("shader_clock_ghz"),
             "note": "cohort-statistics gather, %.0f %% of the step: one gathered fp32 (4 B) per (row, list, member) "
-                    "from LDS-resident rows; peak = conflict-free LDS read rate (256 B/clk/CU).  The loop is bound "
-                    "by instruction issue, not LDS bytes: per 8 gathered bytes a SIMD issues one address op, one "
-                    "ds_read_b64 and four plain f32 ops; the walk alone sustains 0.315 of this peak (12.7 us per "
-                    "round of 1024 lists, tools/gather_overhead.py), a workgroup pays 11 us on top for its row fill "
-                    "and the uneven finish of its waves"
+                    "from LDS-resident rows; peak = conflict-free LDS read rate (256 B/clk/CU) at the nominal "
+                    "2.4 GHz.  The loop is bound by instruction issue, not LDS bytes: per 8 gathered bytes a SIMD "
+                    "issues one address op, one ds_read_b64 and four plain f32 ops; the walk alone sustains 0.33 of "
+                    "this peak (12.1 us per round of 1024 lists, tools/gather_overhead.py), a workgroup pays 13 us "
+                    "on top for its row fill, the uneven finish of its waves and the turnaround.  The kernel runs at "
+                    "the clock the power budget of the box leaves it (shader_clock_ghz, measured inside the timed "
+                    "launches: shader cycles over the constant 100 MHz clock); boxes differ in it"
                     % (100.0 * g["avg_launch_ms"] * g["launches_per_step"] / (dt * 1e3))}
     if "sink" in st:
         out["sink"] = st["sink"]

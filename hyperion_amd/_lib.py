@@ -148,6 +148,7 @@ SIGNATURES = {
                                                 ctypes.c_float, c_void_p, i64, c_void_p, i64, c_void_p, i64,
                                                 c_void_p]),
     "hypmi_gather_redo_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
+    "hypmi_gather_clock": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
     "hypmi_asnorm_apply": (ctypes.c_int, [c_void_p, i64, i64, i64, c_void_p, c_void_p, i64, c_void_p,
                                           c_void_p, i64, c_void_p, i64, c_void_p]),
     "hypmi_asnorm_refine": (ctypes.c_int, [c_void_p, i64, c_void_p, i64, c_void_p, i64, i64, i64, ctypes.c_int,

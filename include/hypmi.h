@@ -351,6 +351,14 @@ int hypmi_gather_apply_seg(const float* X, int64_t n_rows, int nc, int64_t ldx, 
  * device; synchronises with it).  No counterpart in the reference. */
 int hypmi_gather_redo_count(unsigned long long* count, int reset);
 
+/* Diagnostic: the shader clock (GHz) the LDS-resident gather kernels of hypmi_gather_stats / _pairs / _apply*
+ * have run at since the last reset, on the current device: shader cycles over ticks of the constant 100 MHz
+ * clock, summed over the first wave of every workgroup (0 if none has run; synchronises with the device).
+ * These kernels run at the clock the chip's power budget leaves them, which differs between score
+ * distributions and between boxes; the number tells a slow box from a slow build.  No counterpart in the
+ * reference. */
+int hypmi_gather_clock(double* ghz, int reset);
+
 /* out[e,t] = ((S - mz[e,t]) iz[e,t] + (S - mt[t,e]) it[t,e]) / sqrt(2)  (adapt_s_norm.py:63,86,88). */
 int hypmi_asnorm_apply(const float* S, int64_t lds, int64_t ne, int64_t nt, const float* mz,
                        const float* iz, int64_t ldz, const float* mt, const float* it, int64_t ldt,

@@ -1159,6 +1159,40 @@ def test_gather_stats_tail_selection_and_constant_members(nc):
 
 
 @pytest.mark.gpu
+def test_gather_clock_diagnostic_and_rounded_rows():
+    """hypmi_gather_clock: zero after a reset, a plausible shader clock after a launch of the LDS-resident
+    gather.  The same launches compare lists of 300 members (walked on rows rounded to 16 bits of mantissa in
+    LDS) and of 200 (unrounded rows) with float64 statistics: both within 2e-6 of a standard deviation in the
+    mean and 2e-5 in the deviation."""
+    import ctypes
+
+    import torch
+
+    from hyperion_amd import _lib
+    from hyperion_amd.score_norm.adapt_s_norm import gather_stats, lists_to_numpy, topk_rows
+
+    rng = np.random.RandomState(11)
+    nc, rows, lists = 20000, 64, 2048
+    X = (rng.randn(rows, nc) * 7 - 12).astype(np.float32)
+    lib = _lib.load()
+    ghz = ctypes.c_double(-1.0)
+    _lib.check(lib.hypmi_gather_clock(ctypes.byref(ghz), 1))
+    _lib.check(lib.hypmi_gather_clock(ctypes.byref(ghz), 0))
+    assert ghz.value == 0.0
+    for k in (300, 200):
+        idx = topk_rows(torch.from_numpy(rng.randn(lists, nc).astype(np.float32)).cuda(), k, 0)
+        L = lists_to_numpy(idx, k)
+        mean, istd, _ = gather_stats(torch.from_numpy(X).cuda(), None, idx, lists, 1e-5, k)
+        mean, istd = mean[:, :lists].cpu().numpy().astype(np.float64), istd[:, :lists].cpu().numpy().astype(np.float64)
+        sel = X.astype(np.float64)[:, L]
+        m_ref, s_ref = sel.mean(axis=2), sel.std(axis=2)
+        assert np.max(np.abs(mean - m_ref) / s_ref) <= 2e-6, k
+        assert np.max(np.abs(istd * s_ref - 1.0)) <= 2e-5, k
+    _lib.check(lib.hypmi_gather_clock(ctypes.byref(ghz), 0))
+    assert 0.5 < ghz.value < 3.0, ghz.value
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ne,nt,nc,k", [(37, 1500, 600, 50), (130, 70, 20_440, 300), (3, 2100, 30_000, 40),
                                         (260, 1030, 4_000, 9), (6, 20_000, 600, 50),  # lists split over blocks
                                         (131, 70, 45_000, 300), (5, 9_000, 65_535, 24)])  # cohorts taken in segments
