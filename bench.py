@@ -479,7 +479,8 @@ def fp32_only_stage(plda, preproc, cfg):
 
 # ms per step of the default workload on the boxes it has been measured on with one tree (same command):
 # boxes differ by this much in every stage, so differences between runs below it say nothing
-BOX_SPREAD_NOTE = "same tree, same command on different MI355X boxes: 576-625 ms per step (8 %)"
+BOX_SPREAD_NOTE = ("same command on different MI355X boxes: 567-625 ms per step (9 %); the gather follows the shader "
+                   "clock a box sustains under its power cap (roofline.shader_clock_ghz: 2.15-2.23 GHz seen)")
 
 
 def main_asnorm(args, cfg, chain, model, plda, preproc, world, rank, dist):

@@ -352,7 +352,8 @@ int hypmi_gather_apply_seg(const float* X, int64_t n_rows, int nc, int64_t ldx, 
 int hypmi_gather_redo_count(unsigned long long* count, int reset);
 
 /* Diagnostic: the shader clock (GHz) the LDS-resident gather kernels of hypmi_gather_stats / _pairs / _apply*
- * have run at since the last reset, on the current device: shader cycles over ticks of the constant 100 MHz
+ * (cohorts that fit LDS undivided, no mask) have run at since the last reset, on the current device: shader
+ * cycles over ticks of the constant 100 MHz
  * clock, summed over the first wave of every workgroup (0 if none has run; synchronises with the device).
  * These kernels run at the clock the chip's power budget leaves them, which differs between score
  * distributions and between boxes; the number tells a slow box from a slow build.  No counterpart in the
